@@ -1,0 +1,177 @@
+/*
+ * pt_hip.h -- thin C-ABI between the C++ plugin host and the HIP (gfx950) kernels.
+ *
+ * Plain pointers and sizes only: no HIP, torch or C++ types.  Every entry point names the
+ * reference code it replaces (paths relative to the reference tree).  All functions return
+ * PT_OK (0) or a negative pt_status; pt_hip_last_error() gives the text for the calling thread.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  Device pointers are
+ * ordinary HIP device addresses (hipMalloc, or any allocator that hands out device memory).
+ *
+ * Arithmetic contract: IEEE fp32, reference operation order, no FMA contraction, correctly
+ * rounded divide/sqrt (rsqrtf(x) taken as 1.0f/sqrtf(x), helper_math.h:62-65) -- bit-identical
+ * to oracle/pt_oracle.c on the same inputs.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument (null pointer, size mismatch, index out of range) */
+    PT_ERR_HIP = -2,       /* a HIP runtime call failed; text in pt_hip_last_error() */
+    PT_ERR_NOMEM = -3,     /* workspace too small / allocation failed */
+    PT_ERR_STATE = -4,     /* call not valid in the current state */
+    PT_ERR_LIMIT = -5      /* size beyond a documented maximum */
+} pt_status;
+
+/* ---- reference data model, PT_CudaSimple/Structures.cuh:43-69 (same sizes and offsets) ---- */
+typedef struct { float x, y, z, w; } pt_float4;                       /* CUDA float4 */
+typedef struct { pt_float4 position; } pt_vertex;                     /* Vertex, 16 B */
+typedef struct { uint32_t vertexIdx0, vertexIdx1, vertexIdx2, materialIdx; } pt_triangle; /* Triangle, 16 B */
+typedef struct {
+    uint32_t  type;            /* Material::MaterialType: 0 DIFFUSE, 1 REFLECTIVE, 2 EMISSIVE */
+    uint32_t  _pad0[3];
+    pt_float4 color;           /* @16 */
+    float     reflectivity;    /* @32, stored, never read by the reference */
+    uint32_t  _pad1[3];
+} pt_material;                                                        /* Material, 48 B */
+
+enum { PT_MAT_DIFFUSE = 0, PT_MAT_REFLECTIVE = 1, PT_MAT_EMISSIVE = 2 };
+
+/* RNG addressing.  SEQUENTIAL is the reference: one xorshift32 stream per pixel that runs on
+ * from sample to sample (kernels.cu:25-30, Functions.cuh:39-46).  STRIDED starts sample n of
+ * pixel i at step^(i/32 + n*stride)(seed+i): addressable per (pixel, sample), hence splittable
+ * over GPUs; with stride 35 it equals SEQUENTIAL on the default scene (35 draws per sample). */
+enum { PT_RNG_SEQUENTIAL = 0, PT_RNG_STRIDED = 1 };
+
+/* Which kernels execute a render call. */
+enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1 };
+
+#define PT_MAX_DEPTH 32
+#define PT_DEFAULT_DEPTH 10      /* PathTracer.cu:129 */
+#define PT_DEFAULT_SEED 1337u    /* kernels.cu:29 */
+#define PT_DEFAULT_STRIDE 35u    /* 2 + 33 draws: one diffuse bounce, the default scene's constant */
+
+/* What one device renders: the kernel arguments of InitializeRays (kernels.cu:32) plus the
+ * constants the reference bakes in.  Pixels are indexed i = y*width + x, row 0 = bottom row. */
+typedef struct {
+    int32_t   width, height;             /* full image */
+    uint32_t  pixel_first, pixel_count;  /* this device's contiguous pixel range (tile split) */
+    uint32_t  depth;                     /* bounce iterations, 1..PT_MAX_DEPTH */
+    uint32_t  seed;
+    uint32_t  rng_mode;
+    uint32_t  stride;                    /* STRIDED only */
+    pt_float4 origin, top_left, bottom_left, bottom_right;  /* Camera.h:49-77 */
+} pt_frame;
+
+/* Counters a render adds to (device side, 8-byte aligned, PT_STATS_WORDS uint64 words):
+ * [0] rays = extend-stage work items, [1] diffuse bounces shaded,
+ * [2] paths generated, [3] reserved, [4+b] rays at bounce b. */
+#define PT_STATS_WORDS (4 + PT_MAX_DEPTH)
+
+const char* pt_hip_last_error(void);
+
+/* ---- device plumbing (the reference's cudaSetDevice/cudaMalloc/cudaMemcpy/cudaFree/
+ *      cudaDeviceSynchronize calls, PathTracer.cu:25,71-77,88-96,167,217-233) ---- */
+int pt_hip_device_count(int* count);
+int pt_hip_set_device(int device);
+int pt_hip_malloc(void** device_ptr, size_t bytes);
+int pt_hip_free(void* device_ptr);
+int pt_hip_memcpy_h2d(void* device_dst, const void* host_src, size_t bytes, void* stream);
+int pt_hip_memcpy_d2h(void* host_dst, const void* device_src, size_t bytes, void* stream);
+int pt_hip_memset(void* device_dst, int byte_value, size_t bytes, void* stream);
+int pt_hip_fill_f32(float* device_dst, float value, size_t count, void* stream);
+int pt_hip_stream_create(void** stream);
+int pt_hip_stream_destroy(void* stream);
+int pt_hip_stream_synchronize(void* stream);
+int pt_hip_event_create(void** event);
+int pt_hip_event_destroy(void* event);
+int pt_hip_event_record(void* event, void* stream);
+int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* waits for `stop` */
+
+/* ---- scene: Vertex/Triangle/Material arrays (Structures.cuh:43-69, upload PathTracer.cu:48-77)
+ * packed once on the host into the device blob the kernels stage in LDS: per triangle
+ * {v0, e0=v1-v0, e1=v2-v0, n=cross(e0,e1), materialIdx}, per material {type, color}.
+ * Validates vertex and material indices.  The blob is position independent: copy it to the
+ * device with pt_hip_memcpy_h2d.  Entry points that take `scene_blob` also take the triangle and
+ * material counts it was packed with. */
+size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials);
+int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
+                      const pt_triangle* triangles, uint32_t n_triangles,
+                      const pt_material* materials, uint32_t n_materials,
+                      void* host_blob, size_t blob_bytes);
+
+/* ---- a1: InitializeRng (kernels.cu:25-30) + RngInit (Functions.cuh:31-38).
+ * rng[k] = step^((pixel_first+k)/32)(seed + pixel_first + k), by O(log) GF(2) jump-ahead
+ * instead of the reference's serial loop. */
+int pt_hip_rng_seed(const pt_frame* frame, uint32_t* rng, void* stream);
+
+/* ---- wavefront stages.  A path queue is three float4 arrays and one uint32 array of
+ * `capacity` entries each: a={o.x,o.y,o.z,d.x}, b={d.y,d.z,best_t,rng bits},
+ * c=throughput (stepBuffer), pid = sample_in_pass*pixel_count + local pixel. ---- */
+typedef struct {
+    void*    a;
+    void*    b;
+    void*    c;
+    uint32_t* pid;
+} pt_queue;
+
+/* a4: InitializeRays (kernels.cu:32-55).  Writes n_samples*pixel_count paths (pid = index,
+ * throughput (1,1,1,1) and best_t FLT_MAX implied) and sets counts[0].
+ * SEQUENTIAL: n_samples must be 1 and rng[] holds the streams (read; written back by shade).
+ * STRIDED: rng[] holds the sample-0 states of pt_hip_rng_seed; sample frame_first+s is reached
+ * by one matrix apply; sample_matrices is device scratch of n_samples*32 words (NULL if SEQUENTIAL). */
+int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samples,
+                    const uint32_t* rng, uint32_t* sample_matrices, pt_queue out, uint32_t* counts, void* stream);
+
+/* a5+a6: TraverseScene + RayIntersectsTriangle (kernels.cu:57-69, Functions.cuh:56-89).
+ * For the first *count entries: closest accepted hit (t > EPSILON && t < best_t, first index
+ * wins ties), written as hit[q] = {t or unchanged best_t, triangle index or 0xFFFFFFFF}. */
+int pt_hip_extend(const void* scene_blob, uint32_t n_triangles, pt_queue in, const uint32_t* count,
+                  uint32_t capacity, void* hit, void* stream);
+
+/* a7+a8+a9: Intersect + GetDiffuseReflection + CompactionArray (kernels.cu:71-94,
+ * Functions.cuh:91-109, Structures.cuh:71-90).  Diffuse hits continue into `out` (wave64
+ * ballot compaction, one atomic per wave on *count_out); every path that ends writes its
+ * radiance[pid] (and, SEQUENTIAL, its rng stream back) exactly once. */
+int pt_hip_shade(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, uint32_t bounce,
+                 pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
+                 pt_queue out, uint32_t* count_out, void* radiance, uint32_t* rng, void* stream);
+
+/* a10: DrawToTexture (kernels.cu:4-19), the fp32 running mean, for n_samples in order:
+ * mean = frame*r + (mean*n)*r, r = 1/(n+1), n = mean_first + s. */
+int pt_hip_accumulate(uint32_t pixel_count, uint32_t mean_first, uint32_t n_samples,
+                      const void* radiance, void* mean, void* stream);
+
+/* a11: the kernel sequence of PathTracer::BeginDrawing (PathTracer.cu:116-157) for n_samples
+ * samples, no host synchronisation inside.  frame_first = RNG sample index of the first sample
+ * (STRIDED), mean_first = samples already in `mean` (the reference's frameNumber).
+ * workspace: pt_hip_wavefront_workspace_bytes(pixel_count, samples_per_pass, depth) bytes. */
+size_t pt_hip_wavefront_workspace_bytes(uint32_t pixel_count, uint32_t samples_per_pass, uint32_t depth);
+int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                            uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                            uint32_t samples_per_pass, uint32_t* rng, void* mean,
+                            void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
+
+/* The same samples with the whole recurrence of one pixel kept in registers (one lane per
+ * pixel, samples in order; no queues, no HBM traffic between stages).  Same results, bit for
+ * bit, as pt_hip_render_wavefront. */
+int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                        uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                        uint32_t* rng, void* mean, uint64_t* stats, void* stream);
+
+/* Sample-split combine (no reference counterpart: the reference is single-GPU).
+ * out = (fixed-order pairwise tree sum of `shards` means laid out shard-major) * 1/shards. */
+int pt_hip_combine_shards(const void* shard_means, uint32_t shards, size_t n_pixels,
+                          void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+/*
+ * pt_plugin.h -- C-ABI of the HIP path-tracer plugin (libPT_HipWavefront.so).
+ *
+ * The plugin is a drop-in for the reference's PT_CudaSimple DLL: it exports
+ *     IPathTracer* Create(unsigned glTexture, int w, int h, const CameraData*);
+ *     void         Destroy(IPathTracer*);
+ * (reference PT_CudaSimple/PathTracer.cuh:69-76, typedefs include/IPathTracer.h:13-14) and the
+ * object it returns implements the four virtuals of include/IPathTracer.h:7-10.
+ *
+ * Everything below is ADDITIVE.  The reference shows its image through an OpenGL texture
+ * (cudaGraphicsGLRegisterImage, PathTracer.cu:199-209); MI355X has no display path, so the
+ * running mean lives in a device buffer and pt_readback / pt_device_mean hand it out.  The
+ * reference bakes depth 10, seed 1337, 4 triangles and 1 sample per frame into its source
+ * (PathTracer.cu:129,133; kernels.cu:29); pt_set_options / pt_set_scene make them run-time
+ * values whose defaults are the reference's constants.  The pt_update .. pt_resize shims call
+ * the four virtuals for hosts whose FFI cannot call through a C++ vtable (ctypes, cgo, JNI).
+ *
+ * All functions return PT_OK (0) or a negative pt_status (pt_hip.h); pt_last_error() gives
+ * the text.  Handles are the IPathTracer* returned by Create.  Not thread-safe per handle
+ * (the reference is single-threaded).
+ */
+#ifndef PT_PLUGIN_H
+#define PT_PLUGIN_H
+
+#include "pt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void pt_handle;   /* IPathTracer* */
+
+/* CameraData as a C struct: same 36 bytes as include/CameraData.h:14-18. */
+typedef struct {
+    float position[4];       /* x, y, z, w   default (0,0,0,1) */
+    float rotation[4];       /* x, y, z, w   default identity (0,0,0,1) */
+    float fieldOfView;       /* degrees, vertical, default 90 */
+} pt_camera_data;
+
+typedef struct {
+    uint32_t engine;             /* PT_ENGINE_FUSED (default) or PT_ENGINE_WAVEFRONT */
+    uint32_t rng_mode;           /* PT_RNG_SEQUENTIAL (default, the reference) or PT_RNG_STRIDED */
+    uint32_t stride;             /* STRIDED: draws reserved per sample (default 35) */
+    uint32_t depth;              /* bounce iterations, default 10 (PathTracer.cu:129) */
+    uint32_t seed;               /* default 1337 (kernels.cu:29) */
+    uint32_t samples_per_begin;  /* samples one BeginDrawing adds, default 1 (the reference) */
+    uint32_t samples_per_pass;   /* wavefront + STRIDED: samples batched per pass, default 8 */
+    int32_t  device;             /* HIP device ordinal, default: the current device */
+    uint32_t pixel_first;        /* tile split: first pixel index rendered by this instance */
+    uint32_t pixel_count;        /* 0 = the whole image */
+    uint32_t sample_offset;      /* STRIDED sample split: RNG index of this instance's first sample */
+    uint32_t _reserved;
+} pt_options;
+
+typedef struct {
+    uint64_t rays;               /* extend-stage work items since the last restart */
+    uint64_t diffuse_bounces;    /* DIFFUSE shades: each consumed 33 draws on the default scene */
+    uint64_t paths;              /* pixel-samples generated */
+    uint64_t frames;             /* samples per pixel in the running mean (the reference's frameNumber) */
+    uint64_t rays_per_bounce[PT_MAX_DEPTH];  /* wavefront engine only */
+    double   last_render_ms;     /* device time of the last finalized BeginDrawing/pt_render */
+} pt_stats;
+
+const char* pt_last_error(void);
+
+/* HIP device ordinal used by the next Create (the reference takes the GL context's device,
+ * PathTracer.cu:20-25).  -1 (default) = whatever device is current in the calling thread. */
+int pt_set_default_device(int device);
+
+/* C shims over IPathTracer's vtable slots 0..3 (include/IPathTracer.h:7-10). */
+int pt_update(pt_handle* h, const pt_camera_data* camera);
+int pt_begin_drawing(pt_handle* h);
+int pt_finalize_drawing(pt_handle* h);
+int pt_resize(pt_handle* h, int pixel_width, int pixel_height);
+
+/* Options and scene.  Both restart accumulation (like Resize, PathTracer.cu:176-184). */
+int pt_get_options(pt_handle* h, pt_options* out);
+int pt_set_options(pt_handle* h, const pt_options* in);
+/* Replaces the hard-coded scene upload of PathTracer.cu:48-77; reference POD layouts. */
+int pt_set_scene(pt_handle* h, const pt_vertex* vertices, uint32_t n_vertices,
+                 const pt_triangle* triangles, uint32_t n_triangles,
+                 const pt_material* materials, uint32_t n_materials);
+
+/* spp x (BeginDrawing; FinalizeDrawing) as one device submission; honours a pending restart. */
+int pt_render(pt_handle* h, uint32_t spp);
+
+/* Running mean of the instance's pixel range: n_floats = 4 * pixel_count, row 0 = bottom row
+ * (replaces reading the GL texture the reference draws into, kernels.cu:17-18). */
+int pt_readback(pt_handle* h, float* rgba, size_t n_floats);
+/* Per-pixel RNG streams (SEQUENTIAL) or sample-0 states (STRIDED), n = pixel_count. */
+int pt_readback_rng(pt_handle* h, uint32_t* states, size_t n);
+/* Device address of the running mean (float4 x pixel_count), for collectives and zero-copy. */
+void* pt_device_mean(pt_handle* h);
+int pt_get_stats(pt_handle* h, pt_stats* out);
+int pt_get_size(pt_handle* h, int* width, int* height, uint32_t* pixel_first, uint32_t* pixel_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

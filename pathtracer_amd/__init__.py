@@ -1,0 +1,290 @@
+"""pathtracer_amd -- Python binding of the MI355X (gfx950) path-tracer plugin.
+
+The product is the shared library ``libPT_HipWavefront.so`` (C++ host + HIP kernels, built by
+``pathtracer_amd/csrc/Makefile``).  This module only binds its C-ABI (``include/pt_plugin.h``,
+``include/pt_hip.h``) with ctypes, mirroring the reference's plugin interface
+(``include/IPathTracer.h:5-14``: Update / BeginDrawing / FinalizeDrawing / Resize, created by
+``Create`` and released by ``Destroy``).  There is no CPU fallback: if the library is missing or
+no GPU is present the calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_NAME = "libPT_HipWavefront.so"
+LIBRARY_PATH = os.path.join(_HERE, LIBRARY_NAME)
+
+PT_OK = 0
+PT_RNG_SEQUENTIAL, PT_RNG_STRIDED = 0, 1
+PT_ENGINE_WAVEFRONT, PT_ENGINE_FUSED = 0, 1
+PT_MAT_DIFFUSE, PT_MAT_REFLECTIVE, PT_MAT_EMISSIVE = 0, 1, 2
+PT_MAX_DEPTH = 32
+PT_STATS_WORDS = 4 + PT_MAX_DEPTH
+
+
+class PathTracerError(RuntimeError):
+    pass
+
+
+# ---- reference PODs (PT_CudaSimple/Structures.cuh:43-69, include/CameraData.h:14-18) ----
+class Float4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class Vertex(C.Structure):
+    _fields_ = [("position", Float4)]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("vertexIdx0", C.c_uint32), ("vertexIdx1", C.c_uint32), ("vertexIdx2", C.c_uint32), ("materialIdx", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("color", Float4), ("reflectivity", C.c_float), ("_pad1", C.c_uint32 * 3)]
+
+
+class CameraData(C.Structure):
+    _fields_ = [("position", C.c_float * 4), ("rotation", C.c_float * 4), ("fieldOfView", C.c_float)]
+
+    def __init__(self, position=(0.0, 0.0, 0.0, 1.0), rotation=(0.0, 0.0, 0.0, 1.0), fieldOfView=90.0):
+        super().__init__()
+        self.position[:] = position
+        self.rotation[:] = rotation       # x, y, z, w
+        self.fieldOfView = fieldOfView
+
+
+class Frame(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
+                ("depth", C.c_uint32), ("seed", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32),
+                ("origin", Float4), ("top_left", Float4), ("bottom_left", Float4), ("bottom_right", Float4)]
+
+
+class Queue(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("pid", C.c_void_p)]
+
+
+class Options(C.Structure):
+    _fields_ = [("engine", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32), ("depth", C.c_uint32),
+                ("seed", C.c_uint32), ("samples_per_begin", C.c_uint32), ("samples_per_pass", C.c_uint32),
+                ("device", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
+                ("sample_offset", C.c_uint32), ("_reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("diffuse_bounces", C.c_uint64), ("paths", C.c_uint64), ("frames", C.c_uint64),
+                ("rays_per_bounce", C.c_uint64 * PT_MAX_DEPTH), ("last_render_ms", C.c_double)]
+
+
+assert C.sizeof(Vertex) == 16 and C.sizeof(Triangle) == 16 and C.sizeof(Material) == 48 and C.sizeof(CameraData) == 36
+
+# Every symbol include/pt_plugin.h and include/pt_hip.h declare: name -> (restype, argtypes)
+_VP, _U32, _I32, _SZ = C.c_void_p, C.c_uint32, C.c_int32, C.c_size_t
+_FRAMEP, _U32P, _U64P = C.POINTER(Frame), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+SYMBOLS = {
+    # reference exports (PathTracer.cuh:69-76)
+    "Create": (_VP, [C.c_uint, C.c_int, C.c_int, C.POINTER(CameraData)]),
+    "Destroy": (None, [_VP]),
+    # pt_plugin.h
+    "pt_last_error": (C.c_char_p, []),
+    "pt_set_default_device": (C.c_int, [C.c_int]),
+    "pt_update": (C.c_int, [_VP, C.POINTER(CameraData)]),
+    "pt_begin_drawing": (C.c_int, [_VP]),
+    "pt_finalize_drawing": (C.c_int, [_VP]),
+    "pt_resize": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "pt_get_options": (C.c_int, [_VP, C.POINTER(Options)]),
+    "pt_set_options": (C.c_int, [_VP, C.POINTER(Options)]),
+    "pt_set_scene": (C.c_int, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
+    "pt_render": (C.c_int, [_VP, _U32]),
+    "pt_readback": (C.c_int, [_VP, _VP, _SZ]),
+    "pt_readback_rng": (C.c_int, [_VP, _VP, _SZ]),
+    "pt_device_mean": (_VP, [_VP]),
+    "pt_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
+    "pt_get_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), _U32P, _U32P]),
+    # pt_hip.h
+    "pt_hip_last_error": (C.c_char_p, []),
+    "pt_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pt_hip_set_device": (C.c_int, [C.c_int]),
+    "pt_hip_malloc": (C.c_int, [C.POINTER(_VP), _SZ]),
+    "pt_hip_free": (C.c_int, [_VP]),
+    "pt_hip_memcpy_h2d": (C.c_int, [_VP, _VP, _SZ, _VP]),
+    "pt_hip_memcpy_d2h": (C.c_int, [_VP, _VP, _SZ, _VP]),
+    "pt_hip_memset": (C.c_int, [_VP, C.c_int, _SZ, _VP]),
+    "pt_hip_fill_f32": (C.c_int, [_VP, C.c_float, _SZ, _VP]),
+    "pt_hip_stream_create": (C.c_int, [C.POINTER(_VP)]),
+    "pt_hip_stream_destroy": (C.c_int, [_VP]),
+    "pt_hip_stream_synchronize": (C.c_int, [_VP]),
+    "pt_hip_event_create": (C.c_int, [C.POINTER(_VP)]),
+    "pt_hip_event_destroy": (C.c_int, [_VP]),
+    "pt_hip_event_record": (C.c_int, [_VP, _VP]),
+    "pt_hip_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
+    "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),
+    "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
+    "pt_hip_rng_seed": (C.c_int, [_FRAMEP, _VP, _VP]),
+    "pt_hip_generate": (C.c_int, [_FRAMEP, _U32, _U32, _VP, _VP, Queue, _VP, _VP]),
+    "pt_hip_extend": (C.c_int, [_VP, _U32, Queue, _VP, _U32, _VP, _VP]),
+    "pt_hip_shade": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, Queue, _VP, _VP, _U32, Queue, _VP, _VP, _VP, _VP]),
+    "pt_hip_accumulate": (C.c_int, [_U32, _U32, _U32, _VP, _VP, _VP]),
+    "pt_hip_wavefront_workspace_bytes": (_SZ, [_U32, _U32, _U32]),
+    "pt_hip_render_wavefront": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _SZ, _VP, _VP]),
+    "pt_hip_render_fused": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
+    "pt_hip_combine_shards": (C.c_int, [_VP, _U32, _SZ, _VP, _VP]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the plugin and type every export.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("PT_HIP_LIBRARY", LIBRARY_PATH)
+    if not os.path.exists(path):
+        raise PathTracerError(
+            f"{path} not found: build it with `make -C pathtracer_amd/csrc` (needs hipcc); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError names a missing export
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, lib: C.CDLL, what: str, hip_layer: bool = False) -> None:
+    if rc != PT_OK:
+        msg = (lib.pt_hip_last_error() if hip_layer else lib.pt_last_error()) or b""
+        raise PathTracerError(f"{what} failed ({rc}): {msg.decode(errors='replace')}")
+
+
+def default_scene():
+    """The reference's literal scene (PathTracer.cu:48-69) as ctypes arrays."""
+    V = [(-0.5, 0.5, 1.0, 1.0), (0.5, 0.5, 1.0, 1.0), (0.5, -0.5, 1.0, 1.0), (-0.5, -0.5, 1.0, 1.0),
+         (-0.2, 0.5, 0.5, 1.0), (0.2, 0.5, 0.5, 1.0), (0.2, 0.5, 0.9, 1.0), (-0.2, 0.5, 0.9, 1.0)]
+    T = [(0, 1, 2, 0), (2, 3, 0, 0), (4, 5, 6, 1), (6, 7, 4, 1)]
+    return make_scene(V, T, [(PT_MAT_DIFFUSE, (1.0, 0.2, 0.2, 1.0)), (PT_MAT_EMISSIVE, (10.0, 10.0, 10.0, 10.0))])
+
+
+def make_scene(vertices, triangles, materials):
+    """vertices: (x,y,z,w); triangles: (i0,i1,i2,material); materials: (type,(r,g,b,a))."""
+    v = (Vertex * len(vertices))()
+    for k, p in enumerate(vertices):
+        v[k].position = Float4(*[float(c) for c in p])
+    t = (Triangle * len(triangles))()
+    for k, tri in enumerate(triangles):
+        t[k] = Triangle(*[int(c) for c in tri])
+    m = (Material * len(materials))()
+    for k, (ty, col) in enumerate(materials):
+        m[k].type = int(ty)
+        m[k].color = Float4(*[float(c) for c in col])
+    return v, t, m
+
+
+class PathTracer:
+    """The plugin behind the reference's IPathTracer surface, plus the headless extras.
+
+    Method names and call order are the reference's (include/IPathTracer.h:7-10,
+    PathTracer/Program.cpp:57-58,70): ``BeginDrawing(); Update(cam); FinalizeDrawing()``
+    adds one sample per pixel to the running mean.
+    """
+
+    def __init__(self, width: int, height: int, camera: Optional[CameraData] = None, device: Optional[int] = None,
+                 library: Optional[str] = None):
+        self._lib = load_library(library)
+        self._camera = camera or CameraData()
+        if device is not None:
+            self._lib.pt_set_default_device(int(device))
+        self._h = self._lib.Create(0, int(width), int(height), C.byref(self._camera))
+        if device is not None:
+            self._lib.pt_set_default_device(-1)
+        if not self._h:
+            raise PathTracerError("Create failed: " + (self._lib.pt_last_error() or b"").decode(errors="replace"))
+
+    # -- IPathTracer --
+    def Update(self, camera: CameraData) -> None:
+        _check(self._lib.pt_update(self._h, C.byref(camera)), self._lib, "Update")
+
+    def BeginDrawing(self) -> None:
+        _check(self._lib.pt_begin_drawing(self._h), self._lib, "BeginDrawing")
+
+    def FinalizeDrawing(self) -> None:
+        _check(self._lib.pt_finalize_drawing(self._h), self._lib, "FinalizeDrawing")
+
+    def Resize(self, width: int, height: int) -> None:
+        _check(self._lib.pt_resize(self._h, int(width), int(height)), self._lib, "Resize")
+
+    def Destroy(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.Destroy(self._h)
+            self._h = None
+
+    close = Destroy
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.Destroy()
+
+    def __del__(self):
+        try:
+            self.Destroy()
+        except Exception:
+            pass
+
+    # -- headless extras (include/pt_plugin.h) --
+    def get_options(self) -> Options:
+        o = Options()
+        _check(self._lib.pt_get_options(self._h, C.byref(o)), self._lib, "pt_get_options")
+        return o
+
+    def set_options(self, **kw) -> Options:
+        o = self.get_options()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(f"unknown option {k}")
+            setattr(o, k, v)
+        _check(self._lib.pt_set_options(self._h, C.byref(o)), self._lib, "pt_set_options")
+        return o
+
+    def set_scene(self, vertices, triangles, materials) -> None:
+        _check(self._lib.pt_set_scene(self._h, C.cast(vertices, C.c_void_p), len(vertices), C.cast(triangles, C.c_void_p),
+                                      len(triangles), C.cast(materials, C.c_void_p), len(materials)), self._lib, "pt_set_scene")
+
+    def render(self, spp: int) -> None:
+        _check(self._lib.pt_render(self._h, int(spp)), self._lib, "pt_render")
+
+    def size(self):
+        w, h, first, count = C.c_int(), C.c_int(), C.c_uint32(), C.c_uint32()
+        _check(self._lib.pt_get_size(self._h, C.byref(w), C.byref(h), C.byref(first), C.byref(count)), self._lib, "pt_get_size")
+        return w.value, h.value, first.value, count.value
+
+    def readback(self) -> np.ndarray:
+        """Running mean, float32 [pixel_count, 4]; pixel i = y*width + x, row 0 is the bottom row."""
+        _, _, _, count = self.size()
+        out = np.empty((count, 4), dtype=np.float32)
+        _check(self._lib.pt_readback(self._h, out.ctypes.data_as(C.c_void_p), out.size), self._lib, "pt_readback")
+        return out
+
+    def readback_rng(self) -> np.ndarray:
+        _, _, _, count = self.size()
+        out = np.empty(count, dtype=np.uint32)
+        _check(self._lib.pt_readback_rng(self._h, out.ctypes.data_as(C.c_void_p), out.size), self._lib, "pt_readback_rng")
+        return out
+
+    def device_mean(self) -> int:
+        return int(self._lib.pt_device_mean(self._h) or 0)
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _check(self._lib.pt_get_stats(self._h, C.byref(s)), self._lib, "pt_get_stats")
+        return s
+
+
+__all__ = ["PathTracer", "PathTracerError", "CameraData", "Options", "Stats", "Frame", "Queue", "Float4", "Vertex",
+           "Triangle", "Material", "load_library", "default_scene", "make_scene", "SYMBOLS", "LIBRARY_PATH"]

@@ -1,0 +1,192 @@
+// pt_device.hpp -- device-side building blocks shared by the wavefront stages and the fused
+// kernel (gfx950, wave64).  Arithmetic follows the reference operation by operation so that
+// results are bit-identical to the CPU oracle; see the notes on each function.
+//
+// Lane w of the reference's float4 vectors is carried only where it can change a result:
+//  * the primary direction's normalisation (kernels.cu:44, helper_math.h:1314-1318) -- kept;
+//  * GetDiffuseReflection's w = -1 (Functions.cuh:100-108) -- kept (adds exactly 1.0f to the
+//    squared length, gives r.w = -/+ 1/len);
+//  * throughput and radiance (stepBuffer / frameBuffer) are full float4 -- kept;
+//  * everywhere else lane w only ever contributes (finite * 0.0f) = +/-0 to a sum that is then
+//    compared, or is never read; it is dropped.  Inputs are required to be finite.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#pragma clang fp contract(off)
+
+namespace ptd {
+
+constexpr float kEpsilon = 0.000001f;          // Structures.cuh:10
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+
+// ---- xorshift32 (13,17,5): Functions.cuh:41-43 ----
+__host__ __device__ constexpr uint32_t xs_step(uint32_t x) {
+	x ^= x << 13;
+	x ^= x >> 17;
+	x ^= x << 5;
+	return x;
+}
+
+// The step is linear over GF(2).  cols[j][b] = step^(2^j) applied to (1 << b).
+struct JumpTable { uint32_t cols[32][32]; };
+
+__host__ __device__ constexpr uint32_t mat_apply_cx(const uint32_t* cols, uint32_t x) {
+	uint32_t y = 0;
+	for (int b = 0; b < 32; b++)
+		if ((x >> b) & 1u) y ^= cols[b];
+	return y;
+}
+
+constexpr JumpTable make_jump_table() {
+	JumpTable t{};
+	for (int b = 0; b < 32; b++) t.cols[0][b] = xs_step(1u << b);
+	for (int j = 1; j < 32; j++)
+		for (int b = 0; b < 32; b++) t.cols[j][b] = mat_apply_cx(t.cols[j - 1], t.cols[j - 1][b]);
+	return t;
+}
+
+// Branch-free matrix-vector product; `cols` is wave-uniform (scalar loads / LDS broadcast).
+__device__ __forceinline__ uint32_t mat_apply(const uint32_t* __restrict__ cols, uint32_t x) {
+	uint32_t y = 0;
+#pragma unroll
+	for (int b = 0; b < 32; b++) y ^= cols[b] & (0u - ((x >> b) & 1u));
+	return y;
+}
+
+// Functions.cuh:45 : (float)x / (uint)-1.  (uint)-1 converts to 2^32, so this is an exact scale.
+__device__ __forceinline__ float rng_uniform(uint32_t& s) {
+	s = xs_step(s);
+	return (float)s * 2.3283064365386963e-10f;
+}
+
+// helper_math.h:62-65 host form of rsqrtf; HIP's default fp32 divide and sqrt are correctly rounded.
+__device__ __forceinline__ float rsqrt_ref(float x) { return 1.0f / __builtin_sqrtf(x); }
+
+struct Vec3 { float x, y, z; };
+
+__device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {   // Functions.cuh:11-13
+	return Vec3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+__device__ __forceinline__ float dot3(Vec3 a, Vec3 b) {    // helper_math.h:1254 minus the w term
+	return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+
+// One packed triangle: 4 float4 = {v0.xyz,e0.x} {e0.yz,e1.xy} {e1.z,n.xyz} {materialIdx bits,0,0,0}
+struct TriRec { float4 r0, r1, r2, r3; };
+// One packed material: {type bits,0,0,0} {color}
+struct MatRec { float4 head, color; };
+
+struct SceneHeader {
+	uint32_t n_tris, n_mats, tri_offset, mat_offset;   // offsets in bytes from the blob start
+	uint32_t magic, blob_bytes, _pad[2];
+};
+constexpr uint32_t kSceneMagic = 0x50544853u;  // "PTHS"
+
+// Moeller-Trumbore with culling, Functions.cuh:56-89.  Returns true and t unless the reference
+// returns NO_INTERSECTION.  e0/e1 are the precomputed v1-v0 / v2-v0 (same fp32 subtraction).
+__device__ __forceinline__ bool ray_triangle(Vec3 o, Vec3 d, Vec3 v0, Vec3 e0, Vec3 e1, float& t) {
+	Vec3 h = cross3(d, e1);
+	float det = dot3(e0, h);
+	if (det < kEpsilon) return false;            // :72
+	float f = 1.0f / det;                        // :77
+	Vec3 s = Vec3{ o.x - v0.x, o.y - v0.y, o.z - v0.z };
+	float u = f * dot3(s, h);                    // :80
+	if (u < 0.0f || u > 1.0f) return false;
+	Vec3 q = cross3(s, e0);
+	float v = f * dot3(d, q);                    // :84
+	if (v < 0.0f || u + v > 1.0f) return false;
+	t = f * dot3(e1, q);                         // :87
+	return true;
+}
+
+// TraverseScene's loop body for a range of packed triangles (kernels.cu:62-68): closest
+// accepted hit, strict '<' so the first index wins ties; best_t is carried in and out.
+__device__ __forceinline__ void intersect_range(const float4* __restrict__ tris, uint32_t first, uint32_t n,
+                                                Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri) {
+	for (uint32_t k = 0; k < n; k++) {
+		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
+		float t;
+		if (ray_triangle(o, d, Vec3{ r0.x, r0.y, r0.z }, Vec3{ r0.w, r1.x, r1.y }, Vec3{ r1.z, r1.w, r2.x }, t)) {
+			if (t > kEpsilon && t < best_t) { best_t = t; hit_tri = first + k; }   // :64
+		}
+	}
+}
+
+// GetDiffuseReflection, Functions.cuh:91-109: up to 11 rounds of 3 draws (x, y, z in that order),
+// the last round's sample is used.  A round c <= 10 ends the loop only if
+// ((x^2+y^2)+z^2)+1 <= 1, which needs every |2u-1| < 2.5e-4, i.e. the raw draw within 2^20 of
+// 2^31; rounds whose first draw is outside that window skip the float test (exact filter).
+__device__ __forceinline__ void diffuse_reflection(Vec3 n, uint32_t& rng, Vec3& r, float& rw) {
+	uint32_t x = rng, x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll 1
+	for (uint32_t c = 1;; c++) {
+		x = xs_step(x); x0 = x;
+		x = xs_step(x); x1 = x;
+		x = xs_step(x); x2 = x;
+		if (c > 10) break;
+		if ((x0 - 0x7FF00000u) <= 0x00200000u) {
+			float ax = (float)x0 * 2.3283064365386963e-10f * 2.0f - 1.0f;
+			float ay = (float)x1 * 2.3283064365386963e-10f * 2.0f - 1.0f;
+			float az = (float)x2 * 2.3283064365386963e-10f * 2.0f - 1.0f;
+			float len2 = ax * ax + ay * ay + az * az + 1.0f;      // w = -1 (Functions.cuh:101)
+			if (!(len2 > 1.0f)) break;                            // :104
+		}
+	}
+	rng = x;
+	float ax = (float)x0 * 2.3283064365386963e-10f * 2.0f - 1.0f;   // :100-101
+	float ay = (float)x1 * 2.3283064365386963e-10f * 2.0f - 1.0f;
+	float az = (float)x2 * 2.3283064365386963e-10f * 2.0f - 1.0f;
+	float inv = rsqrt_ref(ax * ax + ay * ay + az * az + 1.0f);      // :107
+	ax *= inv; ay *= inv; az *= inv;
+	float aw = -1.0f * inv;
+	// :108  dot(result, normal) > 0 ; the dropped w term is (aw * +0) = -0, an exact identity
+	bool keep = (ax * n.x + ay * n.y + az * n.z) > 0.0f;
+	r = keep ? Vec3{ ax, ay, az } : Vec3{ -ax, -ay, -az };
+	rw = keep ? aw : -aw;
+}
+
+// The DIFFUSE arm of Intersect, kernels.cu:80-84.
+__device__ __forceinline__ void shade_diffuse(Vec3 n, float4 color, float t, Vec3& o, Vec3& d, float4& step, uint32_t& rng) {
+	Vec3 r; float rw;
+	diffuse_reflection(n, rng, r, rw);
+	o.x = o.x + (d.x * t + r.x * kEpsilon);      // :81
+	o.y = o.y + (d.y * t + r.y * kEpsilon);
+	o.z = o.z + (d.z * t + r.z * kEpsilon);
+	d = r;                                       // :82
+	// :84  dot(normal, reflection) with normal.w = +0: the w term is +/-0 and can flip -0 to +0
+	float s = ((n.x * r.x + n.y * r.y + n.z * r.z) + 0.0f * rw) * 2.0f;
+	step.x *= s * color.x; step.y *= s * color.y; step.z *= s * color.z; step.w *= s * color.w;
+}
+
+// InitializeRays' ray set-up, kernels.cu:36-44, all four lanes of the screen point.
+struct FrameDev {
+	int32_t  width, height;
+	uint32_t pixel_first, pixel_count;
+	uint32_t depth, seed, rng_mode, stride;
+	float4   origin, top_left, bottom_left, bottom_right;
+};
+
+__device__ __forceinline__ Vec3 primary_direction(const FrameDev& f, uint32_t px, uint32_t py, uint32_t& rng) {
+	float xs = ((float)px + rng_uniform(rng)) / (float)f.width;    // :39
+	float ys = ((float)py + rng_uniform(rng)) / (float)f.height;   // :40
+	float4 bl = f.bottom_left, br = f.bottom_right, tl = f.top_left;
+	float px4 = (bl.x + (br.x - bl.x) * xs) + (tl.x - bl.x) * ys;  // :44
+	float py4 = (bl.y + (br.y - bl.y) * xs) + (tl.y - bl.y) * ys;
+	float pz4 = (bl.z + (br.z - bl.z) * xs) + (tl.z - bl.z) * ys;
+	float pw4 = (bl.w + (br.w - bl.w) * xs) + (tl.w - bl.w) * ys;
+	float inv = rsqrt_ref(px4 * px4 + py4 * py4 + pz4 * pz4 + pw4 * pw4);
+	return Vec3{ px4 * inv, py4 * inv, pz4 * inv };
+}
+
+// DrawToTexture's running mean, kernels.cu:17-18.
+__device__ __forceinline__ float4 running_mean(float4 color, float4 prev, uint32_t frame_number) {
+	float rcp = 1.0f / (float)(frame_number + 1u);
+	float n = (float)frame_number;
+	return float4{ color.x * rcp + prev.x * n * rcp, color.y * rcp + prev.y * n * rcp,
+	               color.z * rcp + prev.z * n * rcp, color.w * rcp + prev.w * n * rcp };
+}
+
+} // namespace ptd

@@ -1,0 +1,734 @@
+// pt_kernels.hip -- gfx950 kernels of the path-tracing hot path and the pt_hip_* C-ABI
+// (include/pt_hip.h) that launches them.  No CUDA compatibility layer, no CPU fallback:
+// every entry point either runs on the device or returns an error.
+//
+// Wavefront pipeline (reference kernels.cu:25-94 restructured):
+//   rng_seed  -> generate -> [ extend -> shade ] x depth -> accumulate
+// over SoA path queues.  A queue entry is the whole path state (two float4 of ray + best_t +
+// rng, one float4 of throughput, one uint32 path id), so every stage streams coalesced 16-byte
+// lanes; shade moves surviving paths to the other queue with a wave64 ballot/mbcnt prefix and
+// ONE atomic per wave (the reference does one same-address atomicInc per ray and two extra
+// <<<1,1>>> reset launches per bounce).  Per-bounce counters live in one zeroed array, so no
+// reset kernels and no host synchronisation inside a pass.  The scene is packed once and staged
+// in LDS by every block.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pt_hip.h"
+#include "pt_device.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace ptd;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kLdsTriChunk = 1024;                 // 64 KiB of packed triangles per stage
+constexpr uint32_t kShadeLdsMaxTris = 1536;             // shade keeps triangles + materials in LDS up to here
+constexpr uint32_t kShadeLdsMaxMats = 256;
+
+__device__ const JumpTable g_jump = make_jump_table();
+constexpr JumpTable h_jump = make_jump_table();
+
+thread_local std::string t_last_error;
+
+int fail(pt_status code, const std::string& msg) {
+	t_last_error = msg;
+	return (int)code;
+}
+int hip_fail(hipError_t e, const char* what) {
+	return fail(PT_ERR_HIP, std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")");
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
+
+int grid_for(size_t work_items) {
+	static int cus = 0;
+	if (cus == 0) {
+		int dev = 0; hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+		if (cus <= 0) cus = 256;
+	}
+	size_t blocks = (work_items + kBlock - 1) / kBlock;
+	size_t cap = (size_t)cus * 8;                   // 8 blocks of 256 per CU = 32 waves per CU
+	return (int)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+FrameDev to_dev(const pt_frame& f) {
+	FrameDev d;
+	d.width = f.width; d.height = f.height;
+	d.pixel_first = f.pixel_first; d.pixel_count = f.pixel_count;
+	d.depth = f.depth; d.seed = f.seed; d.rng_mode = f.rng_mode; d.stride = f.stride;
+	d.origin = float4{ f.origin.x, f.origin.y, f.origin.z, f.origin.w };
+	d.top_left = float4{ f.top_left.x, f.top_left.y, f.top_left.z, f.top_left.w };
+	d.bottom_left = float4{ f.bottom_left.x, f.bottom_left.y, f.bottom_left.z, f.bottom_left.w };
+	d.bottom_right = float4{ f.bottom_right.x, f.bottom_right.y, f.bottom_right.z, f.bottom_right.w };
+	return d;
+}
+
+int check_frame(const pt_frame* f) {
+	if (!f) return fail(PT_ERR_INVALID, "frame is null");
+	if (f->width <= 0 || f->height <= 0) return fail(PT_ERR_INVALID, "frame width/height must be positive");
+	uint64_t n = (uint64_t)f->width * (uint64_t)f->height;
+	if (n > 0x7FFFFFFFull) return fail(PT_ERR_LIMIT, "image larger than 2^31-1 pixels");
+	if ((uint64_t)f->pixel_first + f->pixel_count > n) return fail(PT_ERR_INVALID, "pixel range exceeds the image");
+	if (f->depth < 1 || f->depth > PT_MAX_DEPTH) return fail(PT_ERR_INVALID, "depth must be 1..PT_MAX_DEPTH");
+	if (f->rng_mode != PT_RNG_SEQUENTIAL && f->rng_mode != PT_RNG_STRIDED) return fail(PT_ERR_INVALID, "unknown rng_mode");
+	if (f->rng_mode == PT_RNG_STRIDED && f->stride == 0) return fail(PT_ERR_INVALID, "stride must be positive in strided mode");
+	return PT_OK;
+}
+
+// step^k as a matrix (host): cols[b] = step^k(1<<b), k reduced modulo the period 2^32-1.
+void host_jump_matrix(uint64_t k, uint32_t cols[32]) {
+	k %= 0xFFFFFFFFull;
+	for (int b = 0; b < 32; b++) {
+		uint32_t x = 1u << b;
+		uint64_t kk = k;
+		for (int j = 0; kk; j++, kk >>= 1)
+			if (kk & 1u) x = mat_apply_cx(h_jump.cols[j], x);
+		cols[b] = x;
+	}
+}
+
+struct JumpMat { uint32_t cols[32]; };
+
+// ------------------------------------------------------------------------------- kernels
+
+// a1. state0(i) = step^(i/32)(seed+i).  Lanes of a wave share at most two exponents.
+__global__ __launch_bounds__(kBlock) void k_rng_seed(uint32_t seed, uint32_t pixel_first, uint32_t n, uint32_t* __restrict__ rng) {
+	for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+		uint32_t i = pixel_first + k;
+		uint32_t x = seed + i;
+		uint32_t e = i >> 5;
+		for (int j = 0; e; j++, e >>= 1)
+			if (e & 1u) x = mat_apply(g_jump.cols[j], x);
+		rng[k] = x;
+	}
+}
+
+// smat[s][b] = step^((frame_first+s)*stride mod 2^32-1)(1<<b): one block of 32 lanes per sample.
+__global__ void k_sample_matrices(uint32_t frame_first, uint32_t stride, uint32_t* __restrict__ smat) {
+	uint32_t s = blockIdx.x, b = threadIdx.x;
+	unsigned long long k = ((unsigned long long)frame_first + s) * stride % 0xFFFFFFFFull;
+	uint32_t x = 1u << b;
+	for (int j = 0; k; j++, k >>= 1)
+		if (k & 1u) x = mat_apply(g_jump.cols[j], x);
+	smat[32u * s + b] = x;
+}
+
+// a4. One thread per path p = s*pixel_count + local pixel; blockIdx.y = sample in pass.
+template <bool STRIDED>
+__global__ __launch_bounds__(kBlock) void k_generate(FrameDev f, const uint32_t* __restrict__ smat,
+                                                     const uint32_t* __restrict__ rng_in,
+                                                     float4* __restrict__ qa, float4* __restrict__ qb) {
+	uint32_t s = blockIdx.y;
+	// strided: sample s of the pass starts at step^((frame_first+s)*stride) * state0; the matrix
+	// is block-uniform (scalar loads), one apply per path
+	const uint32_t* __restrict__ cols = smat + 32u * s;
+	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < f.pixel_count; li += gridDim.x * kBlock) {
+		uint32_t i = f.pixel_first + li;
+		uint32_t rng = rng_in[li];
+		if (STRIDED) rng = mat_apply(cols, rng);
+		uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
+		Vec3 d = primary_direction(f, px, py, rng);
+		size_t p = (size_t)s * f.pixel_count + li;
+		qa[p] = float4{ f.origin.x, f.origin.y, f.origin.z, d.x };
+		qb[p] = float4{ d.y, d.z, FLT_MAX, __uint_as_float(rng) };
+	}
+}
+
+// a5+a6. Scene triangles staged in LDS; one thread per queue entry, block-uniform loops.
+__global__ __launch_bounds__(kBlock) void k_extend(const unsigned char* __restrict__ scene, uint32_t n_tris,
+                                                   const float4* __restrict__ qa, const float4* __restrict__ qb,
+                                                   const uint32_t* __restrict__ count_ptr, uint32_t capacity,
+                                                   uint2* __restrict__ hit) {
+	extern __shared__ float4 s_tris[];
+	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
+	uint32_t count = *count_ptr;
+	if (count > capacity) count = capacity;
+	const bool single = n_tris <= kLdsTriChunk;
+	if (single) {
+		for (uint32_t k = threadIdx.x; k < n_tris * 4; k += kBlock) s_tris[k] = g_tris[k];
+		__syncthreads();
+	}
+	for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+		uint32_t q = base + threadIdx.x;
+		bool active = q < count;
+		float4 a = float4{ 0, 0, 0, 0 }, b = float4{ 0, 0, 0, 0 };
+		if (active) { a = qa[q]; b = qb[q]; }
+		Vec3 o{ a.x, a.y, a.z }, d{ a.w, b.x, b.y };
+		float best = b.z;
+		uint32_t tri = kNoHit;
+		if (single) {
+			if (active) intersect_range(s_tris, 0, n_tris, o, d, best, tri);
+		} else {
+			for (uint32_t c0 = 0; c0 < n_tris; c0 += kLdsTriChunk) {
+				uint32_t cn = min(kLdsTriChunk, n_tris - c0);
+				__syncthreads();
+				for (uint32_t k = threadIdx.x; k < cn * 4; k += kBlock) s_tris[k] = g_tris[(size_t)c0 * 4 + k];
+				__syncthreads();
+				if (active) intersect_range(s_tris, c0, cn, o, d, best, tri);
+			}
+		}
+		if (active) hit[q] = uint2{ __float_as_uint(best), tri };
+	}
+}
+
+// a7+a8+a9.  FIRST: bounce 0 (pid = index, throughput (1,1,1,1) implied, no c/pid reads).
+template <bool FIRST, bool SCENE_LDS>
+__global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
+                                                  uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
+                                                  const float4* __restrict__ qa, const float4* __restrict__ qb,
+                                                  const float4* __restrict__ qc, const uint32_t* __restrict__ qpid,
+                                                  const uint2* __restrict__ hit,
+                                                  const uint32_t* __restrict__ count_ptr, uint32_t capacity,
+                                                  float4* __restrict__ oa, float4* __restrict__ ob,
+                                                  float4* __restrict__ oc, uint32_t* __restrict__ opid,
+                                                  uint32_t* __restrict__ count_out,
+                                                  float4* __restrict__ radiance, uint32_t* __restrict__ rng_out) {
+	extern __shared__ float4 s_scene[];
+	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
+	const float4* g_mats = g_tris + (size_t)n_tris * 4;
+	const float4* tris = g_tris;
+	const float4* mats = g_mats;
+	if (SCENE_LDS) {
+		uint32_t nt4 = n_tris * 4, nm2 = n_mats * 2;
+		for (uint32_t k = threadIdx.x; k < nt4; k += kBlock) s_scene[k] = g_tris[k];
+		for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = g_mats[k];
+		__syncthreads();
+		tris = s_scene; mats = s_scene + nt4;
+	}
+	uint32_t count = *count_ptr;
+	if (count > capacity) count = capacity;
+	const uint32_t lane = threadIdx.x & 63u;
+
+	for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+		uint32_t q = base + threadIdx.x;
+		bool active = q < count;
+		bool cont = false;
+		float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
+		float t = 0.0f;
+		uint32_t rng = 0, pid = q;
+		if (active) {
+			uint2 h = hit[q];
+			float4 a = qa[q], b = qb[q];
+			if (!FIRST) { step = qc[q]; pid = qpid[q]; }
+			o = Vec3{ a.x, a.y, a.z }; d = Vec3{ a.w, b.x, b.y };
+			t = __uint_as_float(h.x);
+			rng = __float_as_uint(b.w);
+			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
+			if (h.y != kNoHit) {
+				float4 r2 = tris[4 * h.y + 2], r3 = tris[4 * h.y + 3];
+				uint32_t m = __float_as_uint(r3.x);
+				uint32_t type = __float_as_uint(mats[2 * m].x);
+				float4 color = mats[2 * m + 1];
+				if (type == PT_MAT_DIFFUSE) {
+					shade_diffuse(Vec3{ r2.y, r2.z, r2.w }, color, t, o, d, step, rng);
+					cont = true;
+				} else if (type == PT_MAT_EMISSIVE) {
+					frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };  // :89
+				}
+				// anything else (REFLECTIVE): absorbed, frame stays (0,0,0,1)   :91-93
+			}
+			if (!cont || last_bounce) {
+				radiance[pid] = frame;
+				if (rng_out) rng_out[pid] = rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
+			}
+		}
+		// wave64 compaction of the continuing paths: one atomic per wave
+		unsigned long long mask = __ballot(cont);
+		uint32_t n_cont = (uint32_t)__popcll(mask);
+		if (n_cont) {
+			uint32_t wave_base = 0;
+			if (lane == 0) wave_base = atomicAdd(count_out, n_cont);
+			wave_base = __shfl(wave_base, 0, 64);
+			if (cont && !last_bounce) {
+				uint32_t pos = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+				oa[pos] = float4{ o.x, o.y, o.z, d.x };
+				ob[pos] = float4{ d.y, d.z, t, __uint_as_float(rng) };
+				oc[pos] = step;
+				opid[pos] = pid;
+			}
+		}
+	}
+}
+
+// a10. One thread per pixel, the pass's samples folded in order.
+__global__ __launch_bounds__(kBlock) void k_accumulate(uint32_t pixel_count, uint32_t mean_first, uint32_t n_samples,
+                                                       const float4* __restrict__ radiance, float4* __restrict__ mean) {
+	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < pixel_count; li += gridDim.x * kBlock) {
+		float4 m = mean[li];
+		for (uint32_t s = 0; s < n_samples; s++)
+			m = running_mean(radiance[(size_t)s * pixel_count + li], m, mean_first + s);
+		mean[li] = m;
+	}
+}
+
+// per-pass counters -> 64-bit totals
+__global__ void k_fold_counts(const uint32_t* __restrict__ counts, uint32_t depth, unsigned long long* __restrict__ stats) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	unsigned long long rays = 0, diffuse = 0;
+	for (uint32_t b = 0; b < depth; b++) { rays += counts[b]; stats[4 + b] += counts[b]; }
+	for (uint32_t b = 1; b <= depth; b++) diffuse += counts[b];
+	stats[0] += rays; stats[1] += diffuse; stats[2] += counts[0];
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_f32(float* __restrict__ dst, float value, size_t n) {
+	for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (size_t)gridDim.x * kBlock) dst[k] = value;
+}
+
+// Fused engine: one lane per pixel, samples in order, all path state in registers.
+template <bool STRIDED, bool SCENE_LDS>
+__global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
+                                                  uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
+                                                  uint32_t mean_first, uint32_t n_samples,
+                                                  uint32_t* __restrict__ rng_io, float4* __restrict__ mean_io,
+                                                  unsigned long long* __restrict__ stats) {
+	extern __shared__ float4 s_scene[];
+	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
+	const float4* mats = tris + (size_t)n_tris * 4;
+	if (SCENE_LDS) {
+		uint32_t nt4 = n_tris * 4, nm2 = n_mats * 2;
+		for (uint32_t k = threadIdx.x; k < nt4; k += kBlock) s_scene[k] = tris[k];
+		for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = mats[k];
+		__syncthreads();
+		tris = s_scene; mats = s_scene + nt4;
+	}
+	uint32_t n_rays = 0, n_diffuse = 0;
+	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < f.pixel_count; li += gridDim.x * kBlock) {
+		uint32_t i = f.pixel_first + li;
+		uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
+		uint32_t start = rng_io[li];
+		if (STRIDED) start = mat_apply(first.cols, start);
+		uint32_t rng = start;
+		float4 m = mean_io[li];
+		for (uint32_t s = 0; s < n_samples; s++) {
+			Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
+			Vec3 d = primary_direction(f, px, py, rng);
+			float best = FLT_MAX;
+			float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
+			for (uint32_t b = 0; b < f.depth; b++) {
+				n_rays++;
+				uint32_t tri = kNoHit;
+				intersect_range(tris, 0, n_tris, o, d, best, tri);
+				if (tri == kNoHit) break;
+				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
+				uint32_t mi = __float_as_uint(r3.x);
+				uint32_t type = __float_as_uint(mats[2 * mi].x);
+				float4 color = mats[2 * mi + 1];
+				if (type == PT_MAT_DIFFUSE) {
+					shade_diffuse(Vec3{ r2.y, r2.z, r2.w }, color, best, o, d, step, rng);
+					n_diffuse++;
+				} else {
+					if (type == PT_MAT_EMISSIVE)
+						frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };
+					break;
+				}
+			}
+			m = running_mean(frame, m, mean_first + s);
+			if (STRIDED) { start = mat_apply(per_sample.cols, start); rng = start; }
+		}
+		mean_io[li] = m;
+		if (!STRIDED) rng_io[li] = rng;
+	}
+	if (stats) {
+		// wave reduce, one 64-bit atomic per wave per counter
+		for (int off = 32; off > 0; off >>= 1) {
+			n_rays += __shfl_down(n_rays, off, 64);
+			n_diffuse += __shfl_down(n_diffuse, off, 64);
+		}
+		if ((threadIdx.x & 63) == 0) {
+			atomicAdd(&stats[0], (unsigned long long)n_rays);
+			atomicAdd(&stats[1], (unsigned long long)n_diffuse);
+		}
+	}
+}
+
+__global__ __launch_bounds__(kBlock) void k_fused_paths_stat(unsigned long long* stats, unsigned long long paths) {
+	if (threadIdx.x == 0 && blockIdx.x == 0) stats[2] += paths;
+}
+
+// Sample-split combine: ((m0+m1)+(m2+m3))+... then * 1/shards, per float lane.
+template <int SHARDS>
+__global__ __launch_bounds__(kBlock) void k_combine(const float4* __restrict__ shard_means, size_t n, float4* __restrict__ out) {
+	const float scale = 1.0f / (float)SHARDS;
+	for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (size_t)gridDim.x * kBlock) {
+		float4 tmp[SHARDS];
+#pragma unroll
+		for (int v = 0; v < SHARDS; v++) tmp[v] = shard_means[(size_t)v * n + k];
+#pragma unroll
+		for (int w = SHARDS; w > 1; w >>= 1) {
+#pragma unroll
+			for (int v = 0; v < w / 2; v++) {
+				float4 a = tmp[2 * v], b = tmp[2 * v + 1];
+				tmp[v] = float4{ a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w };
+			}
+		}
+		out[k] = float4{ tmp[0].x * scale, tmp[0].y * scale, tmp[0].z * scale, tmp[0].w * scale };
+	}
+}
+
+struct SceneInfo { uint32_t n_tris, n_mats; };
+
+
+size_t extend_lds_bytes(uint32_t n_tris) { return (size_t)std::min(n_tris, kLdsTriChunk) * sizeof(TriRec); }
+bool shade_scene_in_lds(const SceneInfo& s) { return s.n_tris <= kShadeLdsMaxTris && s.n_mats <= kShadeLdsMaxMats; }
+size_t shade_lds_bytes(const SceneInfo& s) {
+	return shade_scene_in_lds(s) ? (size_t)s.n_tris * sizeof(TriRec) + (size_t)s.n_mats * sizeof(MatRec) : 0;
+}
+
+// Workspace carve-up of one wavefront pass.
+struct Workspace {
+	float4 *a[2], *b[2], *c[2];
+	uint32_t* pid[2];
+	uint2* hit;
+	float4* radiance;
+	uint32_t* counts;    // PT_MAX_DEPTH + 2 words
+	uint32_t* smat;      // samples_per_pass x 32 words (STRIDED)
+};
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t carve(Workspace* w, unsigned char* base, size_t paths, uint32_t samples_per_pass) {
+	size_t off = 0;
+	auto take = [&](size_t bytes) { unsigned char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+	for (int k = 0; k < 2; k++) {
+		w->a[k] = (float4*)take(paths * 16); w->b[k] = (float4*)take(paths * 16); w->c[k] = (float4*)take(paths * 16);
+		w->pid[k] = (uint32_t*)take(paths * 4);
+	}
+	w->hit = (uint2*)take(paths * 8);
+	w->radiance = (float4*)take(paths * 16);
+	w->counts = (uint32_t*)take((PT_MAX_DEPTH + 2) * 4);
+	w->smat = (uint32_t*)take((size_t)samples_per_pass * 32 * 4);
+	return off;
+}
+
+int launch_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samples, const uint32_t* rng,
+                    uint32_t* smat, float4* qa, float4* qb, hipStream_t stream) {
+	FrameDev f = to_dev(*frame);
+	bool strided = frame->rng_mode == PT_RNG_STRIDED;
+	dim3 grid(grid_for(frame->pixel_count), n_samples);
+	if (strided) {
+		hipLaunchKernelGGL(k_sample_matrices, dim3(n_samples), dim3(32), 0, stream, frame_first, frame->stride, smat);
+		hipLaunchKernelGGL(k_generate<true>, grid, dim3(kBlock), 0, stream, f, (const uint32_t*)smat, rng, qa, qb);
+	} else hipLaunchKernelGGL(k_generate<false>, grid, dim3(kBlock), 0, stream, f, (const uint32_t*)nullptr, rng, qa, qb);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+__global__ void k_set_count(uint32_t* counts, uint32_t n_words, uint32_t first_value) {
+	uint32_t k = threadIdx.x;
+	if (k < n_words) counts[k] = (k == 0) ? first_value : 0u;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------- C-ABI
+
+extern "C" {
+
+const char* pt_hip_last_error(void) { return t_last_error.c_str(); }
+
+int pt_hip_device_count(int* count) {
+	if (!count) return fail(PT_ERR_INVALID, "count is null");
+	HIP_TRY(hipGetDeviceCount(count));
+	return PT_OK;
+}
+int pt_hip_set_device(int device) { HIP_TRY(hipSetDevice(device)); return PT_OK; }
+int pt_hip_malloc(void** device_ptr, size_t bytes) {
+	if (!device_ptr) return fail(PT_ERR_INVALID, "device_ptr is null");
+	*device_ptr = nullptr;
+	if (bytes == 0) return PT_OK;
+	HIP_TRY(hipMalloc(device_ptr, bytes));
+	return PT_OK;
+}
+int pt_hip_free(void* device_ptr) { if (device_ptr) HIP_TRY(hipFree(device_ptr)); return PT_OK; }
+int pt_hip_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream) {
+	if (bytes == 0) return PT_OK;
+	if (!d || !h) return fail(PT_ERR_INVALID, "memcpy_h2d: null pointer");
+	HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+	HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+	return PT_OK;
+}
+int pt_hip_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream) {
+	if (bytes == 0) return PT_OK;
+	if (!d || !h) return fail(PT_ERR_INVALID, "memcpy_d2h: null pointer");
+	HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+	return PT_OK;
+}
+int pt_hip_memset(void* d, int byte_value, size_t bytes, void* stream) {
+	if (bytes == 0) return PT_OK;
+	if (!d) return fail(PT_ERR_INVALID, "memset: null pointer");
+	HIP_TRY(hipMemsetAsync(d, byte_value, bytes, (hipStream_t)stream));
+	return PT_OK;
+}
+int pt_hip_fill_f32(float* d, float value, size_t count, void* stream) {
+	if (count == 0) return PT_OK;
+	if (!d) return fail(PT_ERR_INVALID, "fill_f32: null pointer");
+	hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)stream, d, value, count);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+int pt_hip_stream_create(void** stream) {
+	if (!stream) return fail(PT_ERR_INVALID, "stream is null");
+	hipStream_t s;
+	HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	*stream = (void*)s;
+	return PT_OK;
+}
+int pt_hip_stream_destroy(void* stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return PT_OK; }
+int pt_hip_stream_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return PT_OK; }
+int pt_hip_event_create(void** event) {
+	if (!event) return fail(PT_ERR_INVALID, "event is null");
+	hipEvent_t e;
+	HIP_TRY(hipEventCreate(&e));
+	*event = (void*)e;
+	return PT_OK;
+}
+int pt_hip_event_destroy(void* event) { if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event)); return PT_OK; }
+int pt_hip_event_record(void* event, void* stream) {
+	if (!event) return fail(PT_ERR_INVALID, "event is null");
+	HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+	return PT_OK;
+}
+int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
+	if (!start || !stop || !ms) return fail(PT_ERR_INVALID, "event_elapsed_ms: null pointer");
+	HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+	HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+	return PT_OK;
+}
+
+size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
+	return sizeof(SceneHeader) + (size_t)n_triangles * sizeof(TriRec) + (size_t)n_materials * sizeof(MatRec);
+}
+
+int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
+                      const pt_triangle* triangles, uint32_t n_triangles,
+                      const pt_material* materials, uint32_t n_materials,
+                      void* host_blob, size_t blob_bytes) {
+	if ((!vertices && n_vertices) || (!triangles && n_triangles) || (!materials && n_materials) || !host_blob)
+		return fail(PT_ERR_INVALID, "scene_pack: null pointer");
+	if (blob_bytes < pt_hip_scene_blob_bytes(n_triangles, n_materials)) return fail(PT_ERR_NOMEM, "scene_pack: blob too small");
+	if (n_triangles > (1u << 26)) return fail(PT_ERR_LIMIT, "scene_pack: more than 2^26 triangles");
+	unsigned char* base = (unsigned char*)host_blob;
+	SceneHeader hdr{};
+	hdr.n_tris = n_triangles; hdr.n_mats = n_materials;
+	hdr.tri_offset = (uint32_t)sizeof(SceneHeader);
+	hdr.mat_offset = hdr.tri_offset + n_triangles * (uint32_t)sizeof(TriRec);
+	hdr.magic = kSceneMagic;
+	hdr.blob_bytes = (uint32_t)pt_hip_scene_blob_bytes(n_triangles, n_materials);
+	std::memcpy(base, &hdr, sizeof(hdr));
+	float* tr = (float*)(base + hdr.tri_offset);
+	for (uint32_t k = 0; k < n_triangles; k++) {
+		const pt_triangle& t = triangles[k];
+		if (t.vertexIdx0 >= n_vertices || t.vertexIdx1 >= n_vertices || t.vertexIdx2 >= n_vertices)
+			return fail(PT_ERR_INVALID, "scene_pack: triangle " + std::to_string(k) + " has a vertex index out of range");
+		if (t.materialIdx >= n_materials)
+			return fail(PT_ERR_INVALID, "scene_pack: triangle " + std::to_string(k) + " has a material index out of range");
+		const pt_float4 &v0 = vertices[t.vertexIdx0].position, &v1 = vertices[t.vertexIdx1].position, &v2 = vertices[t.vertexIdx2].position;
+		// Functions.cuh:65-66,88 -- the same fp32 subtractions and cross product, done once
+		float e0x = v1.x - v0.x, e0y = v1.y - v0.y, e0z = v1.z - v0.z;
+		float e1x = v2.x - v0.x, e1y = v2.y - v0.y, e1z = v2.z - v0.z;
+		float nx = e0y * e1z - e0z * e1y, ny = e0z * e1x - e0x * e1z, nz = e0x * e1y - e0y * e1x;
+		float* r = tr + (size_t)k * 16;
+		r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = e0x;
+		r[4] = e0y; r[5] = e0z; r[6] = e1x; r[7] = e1y;
+		r[8] = e1z; r[9] = nx; r[10] = ny; r[11] = nz;
+		uint32_t m = t.materialIdx; std::memcpy(&r[12], &m, 4);
+		r[13] = r[14] = r[15] = 0.0f;
+	}
+	float* mr = (float*)(base + hdr.mat_offset);
+	for (uint32_t k = 0; k < n_materials; k++) {
+		float* r = mr + (size_t)k * 8;
+		uint32_t type = materials[k].type; std::memcpy(&r[0], &type, 4);
+		r[1] = r[2] = r[3] = 0.0f;
+		r[4] = materials[k].color.x; r[5] = materials[k].color.y; r[6] = materials[k].color.z; r[7] = materials[k].color.w;
+	}
+	return PT_OK;
+}
+
+int pt_hip_rng_seed(const pt_frame* frame, uint32_t* rng, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (frame->pixel_count == 0) return PT_OK;
+	if (!rng) return fail(PT_ERR_INVALID, "rng_seed: rng is null");
+	hipLaunchKernelGGL(k_rng_seed, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, (hipStream_t)stream,
+	                   frame->seed, frame->pixel_first, frame->pixel_count, rng);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samples,
+                    const uint32_t* rng, uint32_t* sample_matrices, pt_queue out, uint32_t* counts, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!rng || !out.a || !out.b || !counts) return fail(PT_ERR_INVALID, "generate: null pointer");
+	if (n_samples == 0 || n_samples > 65535) return fail(PT_ERR_INVALID, "generate: n_samples must be 1..65535");
+	if (frame->rng_mode == PT_RNG_SEQUENTIAL && n_samples != 1)
+		return fail(PT_ERR_INVALID, "generate: sequential RNG renders one sample per pass");
+	if (frame->rng_mode == PT_RNG_STRIDED && !sample_matrices)
+		return fail(PT_ERR_INVALID, "generate: strided RNG needs sample_matrices (n_samples*32 words)");
+	if ((uint64_t)n_samples * frame->pixel_count > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "generate: more than 2^32-1 paths per pass");
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, s, counts, (uint32_t)(PT_MAX_DEPTH + 2), n_samples * frame->pixel_count);
+	HIP_TRY(hipGetLastError());
+	if (frame->pixel_count == 0) return PT_OK;
+	return launch_generate(frame, frame_first, n_samples, rng, sample_matrices, (float4*)out.a, (float4*)out.b, s);
+}
+
+int pt_hip_extend(const void* scene_blob, uint32_t n_triangles, pt_queue in, const uint32_t* count, uint32_t capacity, void* hit, void* stream) {
+	if (!scene_blob || !in.a || !in.b || !count || !hit) return fail(PT_ERR_INVALID, "extend: null pointer");
+	if (capacity == 0) return PT_OK;
+	hipLaunchKernelGGL(k_extend, dim3(grid_for(capacity)), dim3(kBlock), extend_lds_bytes(n_triangles), (hipStream_t)stream,
+	                   (const unsigned char*)scene_blob, n_triangles, (const float4*)in.a, (const float4*)in.b, count, capacity, (uint2*)hit);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneInfo& si, uint32_t bounce,
+                        pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
+                        pt_queue out, uint32_t* count_out, void* radiance, uint32_t* rng, hipStream_t s) {
+	uint32_t last = (bounce + 1 >= f.depth) ? 1u : 0u;
+	bool lds = shade_scene_in_lds(si);
+	size_t lds_bytes = shade_lds_bytes(si);
+	dim3 grid(grid_for(capacity)), block(kBlock);
+#define PT_SHADE(FIRST, LDS) hipLaunchKernelGGL((k_shade<FIRST, LDS>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
+	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
+	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, count_out, (float4*)radiance, rng)
+	if (bounce == 0) { if (lds) PT_SHADE(true, true); else PT_SHADE(true, false); }
+	else { if (lds) PT_SHADE(false, true); else PT_SHADE(false, false); }
+#undef PT_SHADE
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+int pt_hip_shade(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, uint32_t bounce,
+                 pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
+                 pt_queue out, uint32_t* count_out, void* radiance, uint32_t* rng, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!scene_blob || !in.a || !in.b || !hit || !count_in || !out.a || !out.b || !out.c || !out.pid || !count_out || !radiance)
+		return fail(PT_ERR_INVALID, "shade: null pointer");
+	if (bounce > 0 && (!in.c || !in.pid)) return fail(PT_ERR_INVALID, "shade: bounce > 0 needs in.c and in.pid");
+	if (bounce >= frame->depth) return fail(PT_ERR_INVALID, "shade: bounce must be < depth");
+	if (frame->rng_mode == PT_RNG_SEQUENTIAL && !rng) return fail(PT_ERR_INVALID, "shade: sequential RNG needs rng");
+	if (capacity == 0) return PT_OK;
+	SceneInfo si{ n_triangles, n_materials };
+	return launch_shade(to_dev(*frame), scene_blob, si, bounce, in, hit, count_in, capacity, out, count_out, radiance,
+	                    frame->rng_mode == PT_RNG_SEQUENTIAL ? rng : nullptr, (hipStream_t)stream);
+}
+
+int pt_hip_accumulate(uint32_t pixel_count, uint32_t mean_first, uint32_t n_samples,
+                      const void* radiance, void* mean, void* stream) {
+	if (pixel_count == 0 || n_samples == 0) return PT_OK;
+	if (!radiance || !mean) return fail(PT_ERR_INVALID, "accumulate: null pointer");
+	hipLaunchKernelGGL(k_accumulate, dim3(grid_for(pixel_count)), dim3(kBlock), 0, (hipStream_t)stream,
+	                   pixel_count, mean_first, n_samples, (const float4*)radiance, (float4*)mean);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+size_t pt_hip_wavefront_workspace_bytes(uint32_t pixel_count, uint32_t samples_per_pass, uint32_t depth) {
+	(void)depth;
+	Workspace w;
+	samples_per_pass = std::max(1u, samples_per_pass);
+	return carve(&w, nullptr, (size_t)pixel_count * samples_per_pass, samples_per_pass);
+}
+
+int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                            uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                            uint32_t samples_per_pass, uint32_t* rng, void* mean,
+                            void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!scene_blob || !rng || !mean || !workspace) return fail(PT_ERR_INVALID, "render_wavefront: null pointer");
+	if (n_samples == 0 || frame->pixel_count == 0) return PT_OK;
+	if (frame->rng_mode == PT_RNG_SEQUENTIAL) samples_per_pass = 1;
+	if (samples_per_pass == 0) samples_per_pass = 1;
+	samples_per_pass = std::min(samples_per_pass, n_samples);
+	if ((uint64_t)samples_per_pass * frame->pixel_count > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "render_wavefront: more than 2^32-1 paths per pass");
+	size_t paths_cap = (size_t)frame->pixel_count * samples_per_pass;
+	Workspace w;
+	if (carve(&w, (unsigned char*)workspace, paths_cap, samples_per_pass) > workspace_bytes) return fail(PT_ERR_NOMEM, "render_wavefront: workspace too small");
+	if (((uintptr_t)workspace & 255u) != 0) return fail(PT_ERR_INVALID, "render_wavefront: workspace must be 256-byte aligned");
+	hipStream_t s = (hipStream_t)stream;
+	SceneInfo si{ n_triangles, n_materials };
+	FrameDev f = to_dev(*frame);
+	const bool sequential = frame->rng_mode == PT_RNG_SEQUENTIAL;
+	const size_t ext_lds = extend_lds_bytes(si.n_tris);
+
+	for (uint32_t done = 0; done < n_samples; done += samples_per_pass) {
+		uint32_t ns = std::min(samples_per_pass, n_samples - done);
+		uint32_t paths = ns * frame->pixel_count;
+		hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, s, w.counts, (uint32_t)(PT_MAX_DEPTH + 2), paths);
+		if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, w.a[0], w.b[0], s)) return rc;
+		int grid = grid_for(paths);
+		for (uint32_t b = 0; b < frame->depth; b++) {
+			int in = b & 1, out = in ^ 1;
+			hipLaunchKernelGGL(k_extend, dim3(grid), dim3(kBlock), ext_lds, s, (const unsigned char*)scene_blob, si.n_tris,
+			                   (const float4*)w.a[in], (const float4*)w.b[in], (const uint32_t*)(w.counts + b), paths, w.hit);
+			pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
+			if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit, w.counts + b, paths, qo, w.counts + b + 1,
+			                          w.radiance, sequential ? rng : nullptr, s)) return rc;
+		}
+		hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
+		                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (float4*)mean);
+		if (stats) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, s, (const uint32_t*)w.counts, frame->depth, (unsigned long long*)stats);
+		HIP_TRY(hipGetLastError());
+	}
+	return PT_OK;
+}
+
+int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                        uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                        uint32_t* rng, void* mean, uint64_t* stats, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!scene_blob || !rng || !mean) return fail(PT_ERR_INVALID, "render_fused: null pointer");
+	if (n_samples == 0 || frame->pixel_count == 0) return PT_OK;
+	hipStream_t s = (hipStream_t)stream;
+	SceneInfo si{ n_triangles, n_materials };
+	FrameDev f = to_dev(*frame);
+	JumpMat first{}, per{};
+	bool strided = frame->rng_mode == PT_RNG_STRIDED;
+	if (strided) {
+		host_jump_matrix((uint64_t)frame_first * frame->stride, first.cols);
+		host_jump_matrix(frame->stride, per.cols);
+	}
+	bool lds = shade_scene_in_lds(si);
+	size_t lds_bytes = shade_lds_bytes(si);
+	dim3 grid(grid_for(frame->pixel_count)), block(kBlock);
+#define PT_FUSED(STR, LDS) hipLaunchKernelGGL((k_fused<STR, LDS>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
+	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
+	if (strided) { if (lds) PT_FUSED(true, true); else PT_FUSED(true, false); }
+	else { if (lds) PT_FUSED(false, true); else PT_FUSED(false, false); }
+#undef PT_FUSED
+	if (stats) hipLaunchKernelGGL(k_fused_paths_stat, dim3(1), dim3(64), 0, s, (unsigned long long*)stats,
+	                              (unsigned long long)n_samples * frame->pixel_count);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+int pt_hip_combine_shards(const void* shard_means, uint32_t shards, size_t n_pixels, void* out, void* stream) {
+	if (!shard_means || !out) return fail(PT_ERR_INVALID, "combine_shards: null pointer");
+	if (shards == 0 || shards > 64 || (shards & (shards - 1))) return fail(PT_ERR_INVALID, "combine_shards: shards must be a power of two <= 16");
+	if (n_pixels == 0) return PT_OK;
+	dim3 grid(grid_for(n_pixels)), block(kBlock);
+	hipStream_t s = (hipStream_t)stream;
+	const float4* in = (const float4*)shard_means;
+	float4* o = (float4*)out;
+	switch (shards) {
+	case 1: hipLaunchKernelGGL(k_combine<1>, grid, block, 0, s, in, n_pixels, o); break;
+	case 2: hipLaunchKernelGGL(k_combine<2>, grid, block, 0, s, in, n_pixels, o); break;
+	case 4: hipLaunchKernelGGL(k_combine<4>, grid, block, 0, s, in, n_pixels, o); break;
+	case 8: hipLaunchKernelGGL(k_combine<8>, grid, block, 0, s, in, n_pixels, o); break;
+	case 16: hipLaunchKernelGGL(k_combine<16>, grid, block, 0, s, in, n_pixels, o); break;
+	default: return fail(PT_ERR_LIMIT, "combine_shards: at most 16 shards");
+	}
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+} // extern "C"
