@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the path-tracing hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[1] -- the reference's default scene
+(PT_CudaSimple/PathTracer.cu:48-69), default camera, 1920x1080, depth 10, seed 1337.  One step =
+one pass of the hot path over one batch: 64 more samples per pixel folded into the running mean
+(the reference's 64 BeginDrawing/FinalizeDrawing pairs), i.e. 2*N*64 = 265.4 M rays per GPU.
+A "ray" is one extend-stage work item; the count comes from device counters.
+
+N > 1 is xGMI sample split with weak scaling: every rank renders 64 *different* samples per
+step of the same frame (strided RNG, stride 35 = reference-exact on this scene), then the ranks'
+running means are combined in a fixed pairwise order (all_to_all of image slices over RCCL ->
+tree combine kernel -> all_gather), so the image is bit-identical whatever N is.
+
+The JSON line also carries `roofline` (algorithmic bytes of the dominant kernel / its device
+time measured with HIP events on the plugin's stream, against the 8 TB/s HBM peak) and
+`cpu_baseline` (the CPU oracle -- a port of the reference path -- timed on this box's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+WIDTH, HEIGHT, SPP_PER_STEP, DEPTH = 1920, 1080, 64, 10
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# SURVEY 8d algorithmic traffic of the wavefront formulation per pixel-sample on the default
+# scene: generate 52 + extend 36 + shade-diffuse 104 + extend 36 + shade-emissive 44*p +
+# accumulate 48 = 276 + 44 p bytes for 2 rays; p = share of secondary rays that reach the light
+# (measured by the oracle at 1080p: 0.0473).
+P_LIGHT = 0.0473
+BYTES_PER_RAY = (276.0 + 44.0 * P_LIGHT) / 2.0
+
+
+def device_tensor(ptr, n_floats, torch):
+    """A torch view of plugin-owned device memory (no copy), via __cuda_array_interface__."""
+    class _Wrap:
+        pass
+    w = _Wrap()
+    w.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(w, device="cuda")
+
+
+def cpu_baseline(spp):
+    """The oracle (kind 'port': our C restatement of the reference path) on the host cores."""
+    from oracle import pt_oracle_py as po
+    po.lib()
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    p = po.params(WIDTH, HEIGHT, depth=DEPTH, spp=spp, threads=cores)
+    n = WIDTH * HEIGHT
+    rng = po.seed_states(1337, n)                       # RNG seeding excluded, as on the GPU side
+    mean = np.ones((n, 4), dtype=np.float32)
+    import ctypes as C
+    v, t, m = po.default_scene()
+    st = po.Stats()
+    t0 = time.perf_counter()
+    rc = po.lib().pto_render(C.byref(p), C.cast(v, C.c_void_p), 8, C.cast(t, C.c_void_p), 4, C.cast(m, C.c_void_p), 2,
+                             None, 0, n, rng.ctypes.data, mean.ctypes.data, None, C.byref(st))
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": round(st.rays / dt / 1e6, 2), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"default scene {WIDTH}x{HEIGHT}, {spp} spp, depth {DEPTH}: {st.rays} rays in {dt:.2f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--engine", choices=["fused", "wavefront"], default="fused")
+    ap.add_argument("--samples-per-pass", type=int, default=8, help="wavefront strided batching")
+    ap.add_argument("--cpu-spp", type=int, default=16, help="samples of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    args = ap.parse_args()
+
+    import torch
+    import pathtracer_amd as pt
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h = args.width, args.height
+    n_pix = w * h
+    engine = pt.PT_ENGINE_FUSED if args.engine == "fused" else pt.PT_ENGINE_WAVEFRONT
+    total_steps = args.warmup + args.steps
+    tracer = pt.PathTracer(w, h, device=local_rank)
+    if world > 1:
+        # rank r owns samples [r*S, (r+1)*S) of the frame, S = all its steps' samples
+        tracer.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, depth=DEPTH,
+                           samples_per_pass=args.samples_per_pass, sample_offset=rank * total_steps * SPP_PER_STEP)
+    elif args.engine == "wavefront":
+        tracer.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, depth=DEPTH, samples_per_pass=args.samples_per_pass)
+    else:
+        tracer.set_options(engine=engine, depth=DEPTH)
+    lib = pt.load_library()
+
+    combine = None
+    if world > 1:
+        assert n_pix % world == 0, "image must split evenly over the ranks"
+        slice_floats = n_pix * 4 // world
+        mean_t = device_tensor(tracer.device_mean(), n_pix * 4, torch)
+        gathered = torch.empty(world * slice_floats, device="cuda", dtype=torch.float32)   # shard-major slices
+        my_slice = torch.empty(slice_floats, device="cuda", dtype=torch.float32)
+        image = torch.empty(n_pix * 4, device="cuda", dtype=torch.float32)
+
+        def combine():
+            dist.all_to_all_single(gathered, mean_t)          # slice j of every rank's mean -> rank j
+            rc = lib.pt_hip_combine_shards(gathered.data_ptr(), world, slice_floats // 4, my_slice.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.pt_hip_last_error()
+            dist.all_gather_into_tensor(image, my_slice)      # every rank ends with the combined frame
+
+    def step():
+        tracer.render(SPP_PER_STEP)                           # blocks until the samples are in the mean
+        if combine:
+            combine()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    st0 = tracer.stats()
+    rays0, ms0, renders0 = st0.rays, st0.total_render_ms, st0.renders
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    st = tracer.stats()
+    rays_rank = st.rays - rays0
+    # average device time of one render = one k_fused launch (or one wavefront pass sequence):
+    # HIP events recorded around it on the plugin's own stream
+    last_ms = (st.total_render_ms - ms0) / max(1, st.renders - renders0)
+
+    if dist:
+        t = torch.tensor([dt, float(rays_rank)], device="cuda", dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, rays_total = float(tmax[0]), float(t[1])
+    else:
+        rays_total = float(rays_rank)
+
+    if rank == 0:
+        rays_per_launch = rays_rank / max(1, args.steps)
+        achieved = rays_per_launch * BYTES_PER_RAY / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.engine}_{w}x{h}_{SPP_PER_STEP}spp")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+bounce)",
+            "value": round(rays_total / dt / 1e6, 1),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "spp_per_s": round(SPP_PER_STEP * world * args.steps / dt, 1),
+            "config": {"workload": f"reference default scene {w}x{h}, {SPP_PER_STEP} spp per step per GPU, depth {DEPTH}, seed 1337 "
+                                   f"(BASELINE.json configs[1])",
+                       "engine": args.engine, "rng": "sequential" if (world == 1 and args.engine == "fused") else "strided/35",
+                       "parallelism": "single GPU" if world == 1 else f"sample split x{world}, fixed-order combine over RCCL"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_fused" if args.engine == "fused" else "wavefront pass (generate+extend+shade+accumulate)",
+                         "kernel_ms": round(last_ms, 4), "algorithmic_bytes_per_ray": round(BYTES_PER_RAY, 2),
+                         "rays_per_launch": int(rays_per_launch)},
+        }
+        if world == 1 and args.cpu_spp > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_spp)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    tracer.Destroy()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,8 +113,13 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 int pt_hip_rng_seed(const pt_frame* frame, uint32_t* rng, void* stream);
 
 /* ---- wavefront stages.  A path queue is three float4 arrays and one uint32 array of
- * `capacity` entries each: a={o.x,o.y,o.z,d.x}, b={d.y,d.z,best_t,rng bits},
- * c=throughput (stepBuffer), pid = sample_in_pass*pixel_count + local pixel. ---- */
+ * `capacity` slots each: a={o.x,o.y,o.z,d.x}, b={d.y,d.z,best_t,rng bits},
+ * c=throughput (stepBuffer), pid = sample_in_pass*pixel_count + local pixel.
+ * Slots are owned block by block: with G = pt_hip_queue_blocks(capacity), block b of every
+ * stage's G-block grid owns slots ((r*G + b)*256 + t), r = 0,1,.., t < 256, dense in its own
+ * index j = r*256 + t, and a counter array holds G words (one per block).  Stages therefore
+ * need no global atomics (the reference's CompactionArray does one same-address atomicInc per
+ * ray, Structures.cuh:74-77).  The same `capacity` must be passed to every stage of a pass. ---- */
 typedef struct {
     void*    a;
     void*    b;
@@ -122,27 +127,33 @@ typedef struct {
     uint32_t* pid;
 } pt_queue;
 
-/* a4: InitializeRays (kernels.cu:32-55).  Writes n_samples*pixel_count paths (pid = index,
- * throughput (1,1,1,1) and best_t FLT_MAX implied) and sets counts[0].
+uint32_t pt_hip_queue_blocks(uint32_t capacity);
+
+/* a4: InitializeRays (kernels.cu:32-55).  Writes path p = s*pixel_count + local pixel to slot p
+ * for s < n_samples (pid = slot, throughput (1,1,1,1) and best_t FLT_MAX implied) and sets the
+ * G words of counts[] to each block's share of those slots.
  * SEQUENTIAL: n_samples must be 1 and rng[] holds the streams (read; written back by shade).
  * STRIDED: rng[] holds the sample-0 states of pt_hip_rng_seed; sample frame_first+s is reached
  * by one matrix apply; sample_matrices is device scratch of n_samples*32 words (NULL if SEQUENTIAL). */
 int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samples,
-                    const uint32_t* rng, uint32_t* sample_matrices, pt_queue out, uint32_t* counts, void* stream);
+                    const uint32_t* rng, uint32_t* sample_matrices, pt_queue out, uint32_t capacity,
+                    uint32_t* counts, void* stream);
 
 /* a5+a6: TraverseScene + RayIntersectsTriangle (kernels.cu:57-69, Functions.cuh:56-89).
- * For the first *count entries: closest accepted hit (t > EPSILON && t < best_t, first index
- * wins ties), written as hit[q] = {t or unchanged best_t, triangle index or 0xFFFFFFFF}. */
-int pt_hip_extend(const void* scene_blob, uint32_t n_triangles, pt_queue in, const uint32_t* count,
+ * For every queued entry (counts[b] per block): closest accepted hit (t > EPSILON && t < best_t,
+ * first index wins ties), written as hit[slot] = {t or unchanged best_t, triangle index or
+ * 0xFFFFFFFF}. */
+int pt_hip_extend(const void* scene_blob, uint32_t n_triangles, pt_queue in, const uint32_t* counts,
                   uint32_t capacity, void* hit, void* stream);
 
 /* a7+a8+a9: Intersect + GetDiffuseReflection + CompactionArray (kernels.cu:71-94,
  * Functions.cuh:91-109, Structures.cuh:71-90).  Diffuse hits continue into `out` (wave64
- * ballot compaction, one atomic per wave on *count_out); every path that ends writes its
- * radiance[pid] (and, SEQUENTIAL, its rng stream back) exactly once. */
+ * ballot + prefix compaction into the block's own slots, one LDS add per wave) and are counted
+ * in counts_out[b]; every path that ends writes its radiance[pid] (and, SEQUENTIAL, its rng
+ * stream back) exactly once. */
 int pt_hip_shade(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, uint32_t bounce,
-                 pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
-                 pt_queue out, uint32_t* count_out, void* radiance, uint32_t* rng, void* stream);
+                 pt_queue in, const void* hit, const uint32_t* counts_in, uint32_t capacity,
+                 pt_queue out, uint32_t* counts_out, void* radiance, uint32_t* rng, void* stream);
 
 /* a10: DrawToTexture (kernels.cu:4-19), the fp32 running mean, for n_samples in order:
  * mean = frame*r + (mean*n)*r, r = 1/(n+1), n = mean_first + s. */

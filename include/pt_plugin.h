@@ -59,6 +59,8 @@ typedef struct {
     uint64_t frames;             /* samples per pixel in the running mean (the reference's frameNumber) */
     uint64_t rays_per_bounce[PT_MAX_DEPTH];  /* wavefront engine only */
     double   last_render_ms;     /* device time of the last finalized BeginDrawing/pt_render */
+    double   total_render_ms;    /* sum of the above since the last restart (HIP events on the plugin's stream) */
+    uint64_t renders;            /* finalized BeginDrawing/pt_render submissions since the last restart */
 } pt_stats;
 
 const char* pt_last_error(void);

@@ -77,7 +77,8 @@ class Options(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("diffuse_bounces", C.c_uint64), ("paths", C.c_uint64), ("frames", C.c_uint64),
-                ("rays_per_bounce", C.c_uint64 * PT_MAX_DEPTH), ("last_render_ms", C.c_double)]
+                ("rays_per_bounce", C.c_uint64 * PT_MAX_DEPTH), ("last_render_ms", C.c_double),
+                ("total_render_ms", C.c_double), ("renders", C.c_uint64)]
 
 
 assert C.sizeof(Vertex) == 16 and C.sizeof(Triangle) == 16 and C.sizeof(Material) == 48 and C.sizeof(CameraData) == 36
@@ -125,7 +126,8 @@ SYMBOLS = {
     "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),
     "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
     "pt_hip_rng_seed": (C.c_int, [_FRAMEP, _VP, _VP]),
-    "pt_hip_generate": (C.c_int, [_FRAMEP, _U32, _U32, _VP, _VP, Queue, _VP, _VP]),
+    "pt_hip_queue_blocks": (_U32, [_U32]),
+    "pt_hip_generate": (C.c_int, [_FRAMEP, _U32, _U32, _VP, _VP, Queue, _U32, _VP, _VP]),
     "pt_hip_extend": (C.c_int, [_VP, _U32, Queue, _VP, _U32, _VP, _VP]),
     "pt_hip_shade": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, Queue, _VP, _VP, _U32, Queue, _VP, _VP, _VP, _VP]),
     "pt_hip_accumulate": (C.c_int, [_U32, _U32, _U32, _VP, _VP, _VP]),

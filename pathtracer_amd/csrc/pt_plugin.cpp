@@ -75,7 +75,8 @@ class PathTracer final : public IPathTracer {
 	void* _stream = nullptr;
 	void* _evStart = nullptr;
 	void* _evStop = nullptr;
-	double _lastMs = 0.0;
+	double _lastMs = 0.0, _totalMs = 0.0;
+	uint64_t _renders = 0;
 	int _error = PT_OK;                 // sticky: once a device call fails the object stops rendering
 
 public:
@@ -142,7 +143,7 @@ public:
 		float ms = 0.0f;
 		if (_inFlightSamples) {
 			if (pt_hip_event_elapsed_ms(_evStart, _evStop, &ms) != PT_OK) { _error = hip_layer_fail(PT_ERR_HIP, "FinalizeDrawing"); return; }
-			_lastMs = ms;
+			_lastMs = ms; _totalMs += ms; _renders++;
 		}
 		if (pt_hip_stream_synchronize(_stream) != PT_OK) { _error = hip_layer_fail(PT_ERR_HIP, "FinalizeDrawing"); return; }
 		_frameNumber += _inFlightSamples;
@@ -242,7 +243,7 @@ public:
 		out->rays = words[0]; out->diffuse_bounces = words[1]; out->paths = words[2];
 		out->frames = _frameNumber;
 		for (int b = 0; b < PT_MAX_DEPTH; b++) out->rays_per_bounce[b] = words[4 + b];
-		out->last_render_ms = _lastMs;
+		out->last_render_ms = _lastMs; out->total_render_ms = _totalMs; out->renders = _renders;
 		return PT_OK;
 	}
 	void Size(int* w, int* h, uint32_t* first, uint32_t* count) const {
@@ -289,6 +290,7 @@ private:
 	int _InitializeRendering() {
 		_shouldRestartRendering = false;
 		_frameNumber = 0;
+		_totalMs = 0.0; _renders = 0;
 		pt_frame f = _Frame();
 		PT_TRY(pt_hip_rng_seed(&f, _dev.rng, _stream));
 		PT_TRY(pt_hip_memset(_dev.stats, 0, PT_STATS_WORDS * sizeof(uint64_t), _stream));
