@@ -104,7 +104,7 @@ def main():
     if world > 1:
         # rank r owns samples [r*S, (r+1)*S) of the frame, S = all its steps' samples
         tracer.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, depth=DEPTH,
-                           samples_per_pass=args.samples_per_pass, sample_offset=rank * total_steps * SPP_PER_STEP)
+                           samples_per_pass=args.samples_per_pass, sample_offset=rank * total_steps * SPP_PER_STEP)   # = sample_split.shard_samples
     elif args.engine == "wavefront":
         tracer.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, depth=DEPTH, samples_per_pass=args.samples_per_pass)
     else:
@@ -117,15 +117,18 @@ def main():
         slice_floats = n_pix * 4 // world
         mean_t = device_tensor(tracer.device_mean(), n_pix * 4, torch)
         gathered = torch.empty(world * slice_floats, device="cuda", dtype=torch.float32)   # shard-major slices
-        my_slice = torch.empty(slice_floats, device="cuda", dtype=torch.float32)
         image = torch.empty(n_pix * 4, device="cuda", dtype=torch.float32)
 
-        def combine():
-            dist.all_to_all_single(gathered, mean_t)          # slice j of every rank's mean -> rank j
-            rc = lib.pt_hip_combine_shards(gathered.data_ptr(), world, slice_floats // 4, my_slice.data_ptr(),
+        from pathtracer_amd import sample_split
+
+        def combine_slices(stacked, shards, n_pix, out_slice):
+            rc = lib.pt_hip_combine_shards(stacked.data_ptr(), shards, n_pix, out_slice.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.pt_hip_last_error()
-            dist.all_gather_into_tensor(image, my_slice)      # every rank ends with the combined frame
+
+        def combine():
+            # all_to_all of image slices -> fixed-order tree on this rank's slice -> all_gather
+            sample_split.exchange_and_combine(mean_t, dist, combine_slices, out=image, scratch=gathered)
 
     def step():
         tracer.render(SPP_PER_STEP)                           # blocks until the samples are in the mean
