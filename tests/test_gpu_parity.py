@@ -56,3 +56,224 @@ def test_strided_35_equals_sequential(pt, oracle, name, engine):
         tr.render(spp)
         img = tr.readback()
     assert_bit_equal(img, ref, name)
+
+
+# ---------------------------------------------------------------- golden fixtures, other scenes, cameras
+import os
+import subprocess
+import sys
+
+import scenes
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _pt_scene(pt, name):
+    return pt.make_scene(*make_golden.scene_of(name))
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("case", sorted(make_golden.CASES))
+def test_gpu_reproduces_golden_vectors(pt, name, engine, case):
+    """The committed vectors (tests/golden, made by the oracle) -- no oracle code runs here."""
+    scene_name, w, h, spp, depth, mode, stride, cam_kw = make_golden.CASES[case]
+    want = np.load(os.path.join(GOLDEN, case + ".npz"))
+    cam = pt.CameraData(cam_kw.get("position", (0, 0, 0, 1)), cam_kw.get("rotation", (0, 0, 0, 1)), cam_kw.get("fov", 90.0))
+    with pt.PathTracer(w, h, camera=cam) as tr:
+        tr.set_scene(*_pt_scene(pt, scene_name))
+        tr.set_options(engine=engine, depth=depth, rng_mode=mode, stride=stride, samples_per_pass=2)
+        tr.render(spp)
+        img, st = tr.readback(), tr.stats()
+        rng = tr.readback_rng()
+    assert_bit_equal(img, want["mean"], f"{case} {name}")
+    assert st.rays == int(want["rays"])
+    assert 2 * st.paths + 33 * st.diffuse_bounces == int(want["draws"])
+    if mode == 0:
+        assert np.array_equal(rng, want["rng"])
+    if engine == 0:
+        assert list(st.rays_per_bounce) == [int(x) for x in want["rays_per_bounce"]]
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_all_materials_depth16(pt, oracle, name, engine):
+    """BASELINE.json configs[4] at test size: DIFFUSE + EMISSIVE + REFLECTIVE(absorbing), depth 16."""
+    V, T, M = scenes.all_materials_scene()
+    w, h, spp = 160, 90, 4
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, depth=16, spp=spp), scene=oracle.make_scene(V, T, M))
+    assert st_ref.rays_per_bounce[4] > 0            # paths really do bounce
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine, depth=16)
+        tr.render(spp)
+        img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+    assert_bit_equal(img, ref, name)
+    assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("n_tris", [12, 300, 1100, 2500])
+def test_synthetic_scenes(pt, oracle, name, engine, n_tris):
+    """BASELINE.json configs[3] at test size; 1100 and 2500 triangles cross the LDS chunk (1024)
+    and the shade-in-LDS (1536) thresholds."""
+    V, T, M = scenes.synthetic_scene(n_tris)
+    w, h, spp = 64, 40, 2
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine)
+        tr.render(spp)
+        img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+    assert_bit_equal(img, ref, f"{name} {len(T)} triangles")
+    assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_empty_scene_and_depth_one(pt, oracle, name, engine):
+    w, h = 32, 16
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene([], [], []))
+        tr.set_options(engine=engine)
+        tr.render(2)
+        img, st = tr.readback(), tr.stats()
+    assert np.array_equal(img, np.tile(np.array([0, 0, 0, 1], dtype=np.float32), (w * h, 1))) and st.rays == w * h * 2
+    ref, _, st_ref, _ = oracle.render(oracle.params(w, h, depth=1, spp=3))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_options(engine=engine, depth=1)
+        tr.render(3)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, ref, name)
+    assert st.rays == st_ref.rays == w * h * 3
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_moved_and_rotated_camera(pt, oracle, name, engine):
+    w, h, spp = 96, 54, 2
+    q = (0.05, -0.12, 0.02, 0.99)      # not normalised on purpose: inverse() divides by |q|^2
+    cam_o = oracle.make_camera(position=(0.1, 0.05, -0.2, 1.0), rotation=q, fov=75.0)
+    ref, _, _, _ = oracle.render(oracle.params(w, h, cam=cam_o, spp=spp))
+    with pt.PathTracer(w, h, camera=pt.CameraData((0.1, 0.05, -0.2, 1.0), q, 75.0)) as tr:
+        tr.set_options(engine=engine)
+        tr.render(spp)
+        img = tr.readback()
+    assert_bit_equal(img, ref, name)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_camera_update_restarts_next_frame(pt, oracle, name, engine):
+    w, h = 64, 36
+    moved = pt.CameraData(fieldOfView=85.0)
+    with pt.PathTracer(w, h) as tr:
+        tr.set_options(engine=engine)
+        for frame in range(5):
+            tr.BeginDrawing()
+            tr.Update(moved if frame >= 2 else pt.CameraData())
+            tr.FinalizeDrawing()
+        img, st = tr.readback(), tr.stats()
+    ref, _, _, _ = oracle.render(oracle.params(w, h, cam=oracle.make_camera(fov=85.0), spp=2))
+    assert_bit_equal(img, ref, name)
+    assert st.frames == 2
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_resize(pt, oracle, name, engine):
+    with pt.PathTracer(64, 36) as tr:
+        tr.set_options(engine=engine)
+        tr.render(2)
+        tr.Resize(50, 30)
+        tr.render(3)
+        img = tr.readback()
+        assert tr.size()[:2] == (50, 30)
+    ref, _, _, _ = oracle.render(oracle.params(50, 30, spp=3))
+    assert_bit_equal(img, ref, name)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_tile_split_is_bit_identical(pt, oracle, name, engine):
+    """SURVEY 8e partitioning B: each instance renders a pixel range with the sequential RNG."""
+    w, h, spp = 80, 45, 3
+    ref, ref_rng, _, _ = oracle.render(oracle.params(w, h, spp=spp))
+    n = w * h
+    cuts = [0, 1000, 1001, 2900, n]
+    parts, rngs = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        with pt.PathTracer(w, h) as tr:
+            tr.set_options(engine=engine, pixel_first=a, pixel_count=b - a)
+            tr.render(spp)
+            parts.append(tr.readback())
+            rngs.append(tr.readback_rng())
+    assert_bit_equal(np.concatenate(parts), ref, name)
+    assert np.array_equal(np.concatenate(rngs), ref_rng)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("shards", [2, 8])
+def test_sample_split_shards_combine_to_sharded_mean(pt, oracle, name, engine, shards):
+    """SURVEY 8e partitioning A on one GPU: `shards` instances stand in for the ranks."""
+    from gpu_util import DeviceBuffer, sync
+    lib = pt.load_library()
+    w, h, per = 64, 32, 3
+    n = w * h
+    stacked = DeviceBuffer(lib, shards * n * 16)
+    host = np.empty((shards, n, 4), dtype=np.float32)
+    for v in range(shards):
+        with pt.PathTracer(w, h) as tr:
+            tr.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, sample_offset=v * per, samples_per_pass=2)
+            tr.render(per)
+            host[v] = tr.readback()
+    stacked.upload(host)
+    out = DeviceBuffer(lib, n * 16)
+    assert lib.pt_hip_combine_shards(stacked.ptr, shards, n, out.ptr, None) == 0
+    sync(lib)
+    got = out.download(np.float32).reshape(n, 4)
+    want, _ = oracle.render_sharded(oracle.params(w, h, rng_mode=oracle.RNG_STRIDED, stride=35, spp=per * shards), shards)
+    assert_bit_equal(got, want, name)
+
+
+def test_hip_plugin_through_the_reference_host_loop(pt, oracle, tmp_path):
+    """The HIP plugin loaded by name through IPathTracerManagement.h and driven by the C++ host
+    loop (tests/host/host_driver.cpp), vtable calls and all."""
+    driver = os.path.join(ROOT, "tests", "host", "host_driver")
+    out = tmp_path / "hip.raw"
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "pathtracer_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([driver, "PT_HipWavefront", "640", "480", "3", str(out), "--resize-at", "1", "320", "200"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.fromfile(out, dtype=np.float32).reshape(-1, 4)
+    ref, _, _, _ = oracle.render(oracle.params(320, 200, spp=2))
+    assert_bit_equal(img, ref, "host loop")
+
+
+def test_engines_agree_at_full_size_and_sampled_pixels_match_oracle(pt, oracle):
+    """BASELINE.json configs[1]: 1920x1080, 64 spp.  Every pixel: fused == wavefront bit for bit.
+    20 000 pixels spread over the image: == oracle bit for bit.  Properties over the whole image:
+    ray count 2*N*spp, every RNG stream advanced by exactly 35*spp steps."""
+    w, h, spp = 1920, 1080, 64
+    n = w * h
+    imgs = {}
+    for name, engine in ENGINES:
+        with pt.PathTracer(w, h) as tr:
+            if engine == 0:
+                tr.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, samples_per_pass=16)
+            else:
+                tr.set_options(engine=engine)
+            tr.render(spp)
+            imgs[name] = tr.readback()
+            st = tr.stats()
+            assert st.rays == 2 * n * spp and st.diffuse_bounces == n * spp
+            if engine == 1:
+                rng = tr.readback_rng()
+    assert_bit_equal(imgs["wavefront"], imgs["fused"], "wavefront vs fused")
+    ids = np.unique(np.concatenate([np.random.default_rng(7).integers(0, n, 20000), [0, w - 1, n - w, n - 1]])).astype(np.uint32)
+    ref, ref_rng, _, _ = oracle.render(oracle.params(w, h, spp=spp), pixel_ids=ids)
+    assert_bit_equal(imgs["fused"][ids], ref, "sampled pixels vs oracle")
+    assert np.array_equal(rng[ids], ref_rng)
+    start = oracle.seed_states(1337, 64, pixel_ids=ids[:64])
+    for k in range(64):
+        assert rng[ids[k]] == oracle.lib().pto_rng_jump(int(start[k]), 35 * spp)
+    img = imgs["fused"]
+    assert np.isfinite(img).all()
+    assert 0.3 < img[:, 0].mean() < 0.45 and abs(img[:, 1].mean() - 0.2 * img[:, 0].mean()) < 1e-4
