@@ -48,6 +48,25 @@ constexpr JumpTable make_jump_table() {
 	return t;
 }
 
+// step^k as four byte-indexed tables: step^k(x) = t[0][x&255] ^ t[1][(x>>8)&255] ^ t[2][(x>>16)&255] ^ t[3][x>>24].
+struct ByteJump { uint32_t t[4][256]; };
+
+constexpr ByteJump make_byte_jump(int steps) {
+	ByteJump r{};
+	for (int j = 0; j < 4; j++)
+		for (uint32_t v = 0; v < 256; v++) {
+			uint32_t x = v << (8 * j);
+			for (int k = 0; k < steps; k++) x = xs_step(x);
+			r.t[j][v] = x;
+		}
+	return r;
+}
+
+// 4 LDS lookups + 3 xors instead of `steps` x 6 VALU ops; `t` points at 1024 words in LDS.
+__device__ __forceinline__ uint32_t byte_jump(const uint32_t* __restrict__ t, uint32_t x) {
+	return t[x & 255u] ^ t[256u + ((x >> 8) & 255u)] ^ t[512u + ((x >> 16) & 255u)] ^ t[768u + (x >> 24)];
+}
+
 // Branch-free matrix-vector product; `cols` is wave-uniform (scalar loads / LDS broadcast).
 __device__ __forceinline__ uint32_t mat_apply(const uint32_t* __restrict__ cols, uint32_t x) {
 	uint32_t y = 0;
@@ -115,31 +134,21 @@ __device__ __forceinline__ void intersect_range(const float4* __restrict__ tris,
 	}
 }
 
-// GetDiffuseReflection, Functions.cuh:91-109: up to 11 rounds of 3 draws (x, y, z in that order),
-// the last round's sample is used.  A round c <= 10 ends the loop only if
-// ((x^2+y^2)+z^2)+1 <= 1, which needs every |2u-1| < 2.5e-4, i.e. the raw draw within 2^20 of
-// 2^31; rounds whose first draw is outside that window skip the float test (exact filter).
-__device__ __forceinline__ void diffuse_reflection(Vec3 n, uint32_t& rng, Vec3& r, float& rw) {
-	uint32_t x = rng, x0 = 0, x1 = 0, x2 = 0;
-#pragma unroll 1
-	for (uint32_t c = 1;; c++) {
-		x = xs_step(x); x0 = x;
-		x = xs_step(x); x1 = x;
-		x = xs_step(x); x2 = x;
-		if (c > 10) break;
-		if ((x0 - 0x7FF00000u) <= 0x00200000u) {
-			float ax = (float)x0 * 2.3283064365386963e-10f * 2.0f - 1.0f;
-			float ay = (float)x1 * 2.3283064365386963e-10f * 2.0f - 1.0f;
-			float az = (float)x2 * 2.3283064365386963e-10f * 2.0f - 1.0f;
-			float len2 = ax * ax + ay * ay + az * az + 1.0f;      // w = -1 (Functions.cuh:101)
-			if (!(len2 > 1.0f)) break;                            // :104
-		}
-	}
-	rng = x;
+// GetDiffuseReflection, Functions.cuh:91-109: rounds of 3 draws (x, y, z in that order) until
+// ((x^2+y^2)+z^2)+1 <= 1 or 11 rounds are done; the last round's sample is used.  w = -1 makes
+// the squared length 1 + |v|^2, so an early end needs every |2u-1| < 2.5e-4 in one round, and an
+// exhaustive scan of all 2^32-1 xorshift32 states (tests/proofs/sampler_never_exits_early.c)
+// shows that never happens: the loop ALWAYS takes 11 rounds = 33 draws.  The 30 discarded draws
+// plus the first kept one are therefore one GF(2) jump, step^31, done by byte tables in LDS.
+__device__ __forceinline__ void diffuse_reflection(Vec3 n, const uint32_t* __restrict__ jump31, uint32_t& rng, Vec3& r, float& rw) {
+	uint32_t x0 = byte_jump(jump31, rng);       // draw 31
+	uint32_t x1 = xs_step(x0);                  // draw 32
+	uint32_t x2 = xs_step(x1);                  // draw 33
+	rng = x2;
 	float ax = (float)x0 * 2.3283064365386963e-10f * 2.0f - 1.0f;   // :100-101
 	float ay = (float)x1 * 2.3283064365386963e-10f * 2.0f - 1.0f;
 	float az = (float)x2 * 2.3283064365386963e-10f * 2.0f - 1.0f;
-	float inv = rsqrt_ref(ax * ax + ay * ay + az * az + 1.0f);      // :107
+	float inv = rsqrt_ref(ax * ax + ay * ay + az * az + 1.0f);      // :107, w = -1 (:101)
 	ax *= inv; ay *= inv; az *= inv;
 	float aw = -1.0f * inv;
 	// :108  dot(result, normal) > 0 ; the dropped w term is (aw * +0) = -0, an exact identity
@@ -149,9 +158,10 @@ __device__ __forceinline__ void diffuse_reflection(Vec3 n, uint32_t& rng, Vec3& 
 }
 
 // The DIFFUSE arm of Intersect, kernels.cu:80-84.
-__device__ __forceinline__ void shade_diffuse(Vec3 n, float4 color, float t, Vec3& o, Vec3& d, float4& step, uint32_t& rng) {
+__device__ __forceinline__ void shade_diffuse(Vec3 n, float4 color, float t, const uint32_t* __restrict__ jump31,
+                                              Vec3& o, Vec3& d, float4& step, uint32_t& rng) {
 	Vec3 r; float rw;
-	diffuse_reflection(n, rng, r, rw);
+	diffuse_reflection(n, jump31, rng, r, rw);
 	o.x = o.x + (d.x * t + r.x * kEpsilon);      // :81
 	o.y = o.y + (d.y * t + r.y * kEpsilon);
 	o.z = o.z + (d.z * t + r.z * kEpsilon);
