@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--engine", choices=["fused", "wavefront"], default="fused")
-    ap.add_argument("--samples-per-pass", type=int, default=8, help="wavefront strided batching")
+    ap.add_argument("--samples-per-pass", type=int, default=16, help="wavefront strided batching")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples of the CPU baseline leg (0 = skip)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)

@@ -134,10 +134,12 @@ uint32_t pt_hip_queue_blocks(uint32_t capacity);
  * G words of counts[] to each block's share of those slots.
  * SEQUENTIAL: n_samples must be 1 and rng[] holds the streams (read; written back by shade).
  * STRIDED: rng[] holds the sample-0 states of pt_hip_rng_seed; sample frame_first+s is reached
- * by one matrix apply; sample_matrices is device scratch of n_samples*32 words (NULL if SEQUENTIAL). */
+ * by one matrix apply; sample_matrices is device scratch of n_samples*32 words (NULL if SEQUENTIAL).
+ * hit != NULL (scene of at most 1536 triangles, staged in LDS): the primary ray is also intersected
+ * here, as pt_hip_extend would, and hit[slot] written -- no extend pass is needed for bounce 0. */
 int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samples,
-                    const uint32_t* rng, uint32_t* sample_matrices, pt_queue out, uint32_t capacity,
-                    uint32_t* counts, void* stream);
+                    const uint32_t* rng, uint32_t* sample_matrices, const void* scene_blob, uint32_t n_triangles,
+                    pt_queue out, void* hit, uint32_t capacity, uint32_t* counts, void* stream);
 
 /* a5+a6: TraverseScene + RayIntersectsTriangle (kernels.cu:57-69, Functions.cuh:56-89).
  * For every queued entry (counts[b] per block): closest accepted hit (t > EPSILON && t < best_t,
@@ -150,10 +152,11 @@ int pt_hip_extend(const void* scene_blob, uint32_t n_triangles, pt_queue in, con
  * Functions.cuh:91-109, Structures.cuh:71-90).  Diffuse hits continue into `out` (wave64
  * ballot + prefix compaction into the block's own slots, one LDS add per wave) and are counted
  * in counts_out[b]; every path that ends writes its radiance[pid] (and, SEQUENTIAL, its rng
- * stream back) exactly once. */
+ * stream back) exactly once.  hit_out != NULL (scene fits LDS): each continuing ray is intersected at
+ * once and hit_out[slot of the continuing path] written, so the next bounce needs no extend pass. */
 int pt_hip_shade(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, uint32_t bounce,
                  pt_queue in, const void* hit, const uint32_t* counts_in, uint32_t capacity,
-                 pt_queue out, uint32_t* counts_out, void* radiance, uint32_t* rng, void* stream);
+                 pt_queue out, void* hit_out, uint32_t* counts_out, void* radiance, uint32_t* rng, void* stream);
 
 /* a10: DrawToTexture (kernels.cu:4-19), the fp32 running mean, for n_samples in order:
  * mean = frame*r + (mean*n)*r, r = 1/(n+1), n = mean_first + s. */

@@ -88,7 +88,7 @@ public:
 		_opt.depth = PT_DEFAULT_DEPTH;
 		_opt.seed = PT_DEFAULT_SEED;
 		_opt.samples_per_begin = 1;
-		_opt.samples_per_pass = 8;
+		_opt.samples_per_pass = 16;
 		_opt.device = -1;
 	}
 

@@ -41,9 +41,10 @@ def _oracle_paths(oracle, p, n_pix, pixel_first, n_samples, frame_first, rng0, s
     return paths
 
 
+@pytest.mark.parametrize("fuse", [False, True], ids=["separate-extend", "fused-extend"])
 @pytest.mark.parametrize("scene_name,strided,n_samples,depth", [("default", False, 1, 10), ("default", True, 3, 10),
                                                                 ("allmat", False, 1, 16), ("allmat", True, 2, 6)])
-def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_samples, depth):
+def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_samples, depth, fuse):
     lib, L = pt.load_library(), oracle.lib()
     w, h, pixel_first, n_pix = 40, 24, 100, 700
     V, T, M = scenes.default_scene() if scene_name == "default" else scenes.all_materials_scene()
@@ -64,12 +65,13 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
     q = [dict(a=DeviceBuffer(lib, P * 16), b=DeviceBuffer(lib, P * 16), c=DeviceBuffer(lib, P * 16), pid=DeviceBuffer(lib, P * 4)) for _ in range(2)]
     Q = [pt.Queue(a=x["a"].ptr, b=x["b"].ptr, c=x["c"].ptr, pid=x["pid"].ptr) for x in q]
     counts = DeviceBuffer(lib, (depth + 2) * G * 4)
-    hit = DeviceBuffer(lib, P * 8)
+    hits = [DeviceBuffer(lib, P * 8), DeviceBuffer(lib, P * 8)]
     radiance = DeviceBuffer(lib, P * 16).upload(np.full(P * 4, np.nan, dtype=np.float32))
     smat = DeviceBuffer(lib, n_samples * 32 * 4)
 
     # ---- generate (a4)
-    rc = lib.pt_hip_generate(C.byref(fr), frame_first, n_samples, rng.ptr, smat.ptr if strided else None, Q[0], P, counts.ptr, None)
+    rc = lib.pt_hip_generate(C.byref(fr), frame_first, n_samples, rng.ptr, smat.ptr if strided else None, scene_dev.ptr, len(T),
+                             Q[0], hits[0].ptr if fuse else None, P, counts.ptr, None)
     assert rc == 0, lib.pt_hip_last_error()
     sync(lib)
     paths = _oracle_paths(oracle, p, n_pix, pixel_first, n_samples, frame_first, rng0, strided, scene_o)
@@ -91,8 +93,10 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
         i_in, i_out = bounce & 1, (bounce & 1) ^ 1
         cin = C.c_void_p(counts.ptr + bounce * G * 4)
         cout = C.c_void_p(counts.ptr + (bounce + 1) * G * 4)
-        rc = lib.pt_hip_extend(scene_dev.ptr, len(T), Q[i_in], cin, P, hit.ptr, None)
-        assert rc == 0, lib.pt_hip_last_error()
+        hit = hits[i_in]
+        if not fuse:
+            rc = lib.pt_hip_extend(scene_dev.ptr, len(T), Q[i_in], cin, P, hit.ptr, None)
+            assert rc == 0, lib.pt_hip_last_error()
         sync(lib)
         cnt = counts.download(np.uint32)[bounce * G:(bounce + 1) * G]
         slots = queue_slots(cnt, G)
@@ -106,8 +110,8 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
             want_t = np.array([path.t], dtype=np.float32).view(np.uint32)[0]
             want_tri = 0xFFFFFFFF if path.hit_tri < 0 else path.hit_tri
             assert (H[slot, 0], H[slot, 1]) == (want_t, want_tri), (bounce, int(pid))
-        rc = lib.pt_hip_shade(C.byref(fr), scene_dev.ptr, len(T), len(M), bounce, Q[i_in], hit.ptr, cin, P, Q[i_out], cout,
-                              radiance.ptr, rng.ptr if not strided else None, None)
+        rc = lib.pt_hip_shade(C.byref(fr), scene_dev.ptr, len(T), len(M), bounce, Q[i_in], hit.ptr, cin, P, Q[i_out],
+                              hits[i_out].ptr if fuse else None, cout, radiance.ptr, rng.ptr if not strided else None, None)
         assert rc == 0, lib.pt_hip_last_error()
         sync(lib)
         n_diffuse = 0
@@ -132,7 +136,9 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
                 wb = np.array([x.direction.y, x.direction.z, x.t], dtype=np.float32)
                 wc = np.array(x.step.tuple(), dtype=np.float32)
                 assert np.array_equal(oa[k].view(np.uint32), wa.view(np.uint32)), (bounce, int(pid))
-                assert np.array_equal(ob[k, :3].view(np.uint32), wb.view(np.uint32))
+                # with the fused extend b.z already holds the NEXT bounce's accepted t (checked via hit[] above)
+                ncmp = 2 if fuse else 3
+                assert np.array_equal(ob[k, :ncmp].view(np.uint32), wb[:ncmp].view(np.uint32))
                 assert ob[k, 3:4].view(np.uint32)[0] == x.rng
                 assert np.array_equal(oc[k].view(np.uint32), wc.view(np.uint32))
         if not alive:
