@@ -114,7 +114,9 @@ int pt_hip_rng_seed(const pt_frame* frame, uint32_t* rng, void* stream);
 
 /* ---- wavefront stages.  A path queue is three float4 arrays and one uint32 array of
  * `capacity` slots each: a={o.x,o.y,o.z,d.x}, b={d.y,d.z,best_t,rng bits},
- * c=throughput (stepBuffer), pid = sample_in_pass*pixel_count + local pixel.
+ * c=throughput (stepBuffer), pid = sample_in_pass*pixel_count + local pixel.  The bounce-0 queue
+ * that generate writes is thinner: only b={d.x,d.y,d.z,rng bits}; the origin is the camera's,
+ * best_t is FLT_MAX, throughput (1,1,1,1) and pid = slot are implied (extend/shade with bounce 0).
  * Slots are owned block by block: with G = pt_hip_queue_blocks(capacity), block b of every
  * stage's G-block grid owns slots ((r*G + b)*256 + t), r = 0,1,.., t < 256, dense in its own
  * index j = r*256 + t, and a counter array holds G words (one per block).  Stages therefore
@@ -130,7 +132,7 @@ typedef struct {
 uint32_t pt_hip_queue_blocks(uint32_t capacity);
 
 /* a4: InitializeRays (kernels.cu:32-55).  Writes path p = s*pixel_count + local pixel to slot p
- * for s < n_samples (pid = slot, throughput (1,1,1,1) and best_t FLT_MAX implied) and sets the
+ * for s < n_samples (only out.b is written, see above) and sets the
  * G words of counts[] to each block's share of those slots.
  * SEQUENTIAL: n_samples must be 1 and rng[] holds the streams (read; written back by shade).
  * STRIDED: rng[] holds the sample-0 states of pt_hip_rng_seed; sample frame_first+s is reached
@@ -145,23 +147,24 @@ int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samp
  * For every queued entry (counts[b] per block): closest accepted hit (t > EPSILON && t < best_t,
  * first index wins ties), written as hit[slot] = {t or unchanged best_t, triangle index or
  * 0xFFFFFFFF}. */
-int pt_hip_extend(const void* scene_blob, uint32_t n_triangles, pt_queue in, const uint32_t* counts,
-                  uint32_t capacity, void* hit, void* stream);
+int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob, uint32_t n_triangles, pt_queue in,
+                  const uint32_t* counts, uint32_t capacity, void* hit, void* stream);
 
 /* a7+a8+a9: Intersect + GetDiffuseReflection + CompactionArray (kernels.cu:71-94,
  * Functions.cuh:91-109, Structures.cuh:71-90).  Diffuse hits continue into `out` (wave64
  * ballot + prefix compaction into the block's own slots, one LDS add per wave) and are counted
- * in counts_out[b]; every path that ends writes its radiance[pid] (and, SEQUENTIAL, its rng
- * stream back) exactly once.  hit_out != NULL (scene fits LDS): each continuing ray is intersected at
+ * in counts_out[b]; every path that ends sets lit[pid] (one byte: 1 = it reached an emitter and
+ * radiance[pid] holds the sample, 0 = the sample is (0,0,0,1) and radiance[pid] is not written)
+ * and, SEQUENTIAL, writes its rng stream back -- exactly once.  hit_out != NULL (scene fits LDS): each continuing ray is intersected at
  * once and hit_out[slot of the continuing path] written, so the next bounce needs no extend pass. */
 int pt_hip_shade(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, uint32_t bounce,
                  pt_queue in, const void* hit, const uint32_t* counts_in, uint32_t capacity,
-                 pt_queue out, void* hit_out, uint32_t* counts_out, void* radiance, uint32_t* rng, void* stream);
+                 pt_queue out, void* hit_out, uint32_t* counts_out, void* radiance, void* lit, uint32_t* rng, void* stream);
 
 /* a10: DrawToTexture (kernels.cu:4-19), the fp32 running mean, for n_samples in order:
  * mean = frame*r + (mean*n)*r, r = 1/(n+1), n = mean_first + s. */
 int pt_hip_accumulate(uint32_t pixel_count, uint32_t mean_first, uint32_t n_samples,
-                      const void* radiance, void* mean, void* stream);
+                      const void* radiance, const void* lit, void* mean, void* stream);
 
 /* a11: the kernel sequence of PathTracer::BeginDrawing (PathTracer.cu:116-157) for n_samples
  * samples, no host synchronisation inside.  frame_first = RNG sample index of the first sample

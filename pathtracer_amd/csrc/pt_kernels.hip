@@ -136,7 +136,7 @@ template <bool STRIDED, bool EXTEND>
 __global__ __launch_bounds__(kBlock) void k_generate(FrameDev f, const uint32_t* __restrict__ smat,
                                                      const uint32_t* __restrict__ rng_in,
                                                      const unsigned char* __restrict__ scene, uint32_t n_tris,
-                                                     float4* __restrict__ qa, float4* __restrict__ qb, uint2* __restrict__ hit) {
+                                                     float4* __restrict__ qb, uint2* __restrict__ hit) {
 	extern __shared__ float4 s_tris[];
 	if (EXTEND) {
 		const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev f, const uint32_t*
 		uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
 		Vec3 d = primary_direction(f, px, py, rng);
 		size_t p = (size_t)s * f.pixel_count + li;
-		qa[p] = float4{ f.origin.x, f.origin.y, f.origin.z, d.x };
-		qb[p] = float4{ d.y, d.z, FLT_MAX, __uint_as_float(rng) };
+		// bounce-0 entry: the origin is the camera's (uniform) and best_t is FLT_MAX, neither is stored
+		qb[p] = float4{ d.x, d.y, d.z, __uint_as_float(rng) };
 		if (EXTEND) {
 			float best = FLT_MAX;
 			uint32_t tri = kNoHit;
@@ -187,7 +187,8 @@ __global__ void k_set_count(uint32_t* __restrict__ counts, uint32_t G, uint32_t 
 }
 
 // a5+a6. Scene triangles staged in LDS; one thread per queue entry, block-uniform loops.
-__global__ __launch_bounds__(kBlock) void k_extend(const unsigned char* __restrict__ scene, uint32_t n_tris,
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_extend(float4 origin, const unsigned char* __restrict__ scene, uint32_t n_tris,
                                                    const float4* __restrict__ qa, const float4* __restrict__ qb,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t capacity,
                                                    uint2* __restrict__ hit) {
@@ -204,9 +205,10 @@ __global__ __launch_bounds__(kBlock) void k_extend(const unsigned char* __restri
 		uint32_t q = queue_slot(j0, G) + threadIdx.x;
 		bool active = j0 + threadIdx.x < count && q < capacity;
 		float4 a = float4{ 0, 0, 0, 0 }, b = float4{ 0, 0, 0, 0 };
-		if (active) { a = qa[q]; b = qb[q]; }
-		Vec3 o{ a.x, a.y, a.z }, d{ a.w, b.x, b.y };
-		float best = b.z;
+		if (active) { if (!FIRST) a = qa[q]; b = qb[q]; }
+		Vec3 o = FIRST ? Vec3{ origin.x, origin.y, origin.z } : Vec3{ a.x, a.y, a.z };
+		Vec3 d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
+		float best = FIRST ? FLT_MAX : b.z;
 		uint32_t tri = kNoHit;
 		if (single) {
 			if (active) intersect_range(s_tris, 0, n_tris, o, d, best, tri);
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
                                                   float4* __restrict__ oc, uint32_t* __restrict__ opid,
                                                   uint2* __restrict__ ohit,
                                                   uint32_t* __restrict__ count_out,
-                                                  float4* __restrict__ radiance, uint32_t* __restrict__ rng_out) {
+                                                  float4* __restrict__ radiance, unsigned char* __restrict__ lit,
+                                                  uint32_t* __restrict__ rng_out) {
 	static_assert(!EXTEND || SCENE_LDS, "the fused extend intersects against the LDS copy of the scene");
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
@@ -283,10 +286,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 				color = mats[2 * m + 1];
 				n = Vec3{ r2.y, r2.z, r2.w };
 			}
+			bool emitted = false;
 			if (type == PT_MAT_DIFFUSE) {
-				float4 a = qa[q], b = qb[q];
-				if (!FIRST) step = qc[q];
-				o = Vec3{ a.x, a.y, a.z }; d = Vec3{ a.w, b.x, b.y };
+				float4 b = qb[q];
+				if (FIRST) {
+					o = Vec3{ f.origin.x, f.origin.y, f.origin.z }; d = Vec3{ b.x, b.y, b.z };
+				} else {
+					float4 a = qa[q];
+					step = qc[q];
+					o = Vec3{ a.x, a.y, a.z }; d = Vec3{ a.w, b.x, b.y };
+				}
 				t = __uint_as_float(h.x);
 				rng = __float_as_uint(b.w);
 				shade_diffuse(n, color, t, s_jump, o, d, step, rng);
@@ -296,12 +305,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 				if (type == PT_MAT_EMISSIVE) {
 					if (!FIRST) step = qc[q];
 					frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };  // :89
+					emitted = true;
 				}
 				// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
 				if (rng_out) rng = __float_as_uint(qb[q].w);
 			}
 			if (!cont || last_bounce) {
-				radiance[pid] = frame;
+				// every path that ends sets its flag; only emitter hits carry a radiance, all others are (0,0,0,1)
+				lit[pid] = emitted ? 1 : 0;
+				if (emitted) radiance[pid] = frame;
 				if (rng_out) rng_out[pid] = rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
 			}
 		}
@@ -329,11 +341,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 
 // a10. One thread per pixel, the pass's samples folded in order.
 __global__ __launch_bounds__(kBlock) void k_accumulate(uint32_t pixel_count, uint32_t mean_first, uint32_t n_samples,
-                                                       const float4* __restrict__ radiance, float4* __restrict__ mean) {
+                                                       const float4* __restrict__ radiance, const unsigned char* __restrict__ lit,
+                                                       float4* __restrict__ mean) {
 	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < pixel_count; li += gridDim.x * kBlock) {
 		float4 m = mean[li];
-		for (uint32_t s = 0; s < n_samples; s++)
-			m = running_mean(radiance[(size_t)s * pixel_count + li], m, mean_first + s);
+		for (uint32_t s = 0; s < n_samples; s++) {
+			size_t p = (size_t)s * pixel_count + li;
+			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };        // kernels.cu:49
+			if (lit[p]) frame = radiance[p];
+			m = running_mean(frame, m, mean_first + s);
+		}
 		mean[li] = m;
 	}
 }
@@ -467,6 +484,7 @@ struct Workspace {
 	uint32_t* pid[2];
 	uint2* hit[2];
 	float4* radiance;
+	unsigned char* lit;  // 1 byte per path: 1 = radiance[] holds the sample, 0 = the sample is (0,0,0,1)
 	uint32_t* counts;    // (PT_MAX_DEPTH + 2) x G words: per bounce, per queue block
 	uint32_t* smat;      // samples_per_pass x 32 words (STRIDED)
 };
@@ -480,13 +498,14 @@ size_t carve(Workspace* w, unsigned char* base, size_t paths, uint32_t samples_p
 	}
 	w->hit[0] = (uint2*)take(paths * 8); w->hit[1] = (uint2*)take(paths * 8);
 	w->radiance = (float4*)take(paths * 16);
+	w->lit = (unsigned char*)take(paths);
 	w->counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
 	w->smat = (uint32_t*)take((size_t)samples_per_pass * 32 * 4);
 	return off;
 }
 
 int launch_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samples, const uint32_t* rng,
-                    uint32_t* smat, const void* scene_blob, uint32_t n_tris, float4* qa, float4* qb, uint2* hit, hipStream_t stream) {
+                    uint32_t* smat, const void* scene_blob, uint32_t n_tris, float4* qb, uint2* hit, hipStream_t stream) {
 	FrameDev f = to_dev(*frame);
 	bool strided = frame->rng_mode == PT_RNG_STRIDED;
 	bool extend = hit != nullptr;
@@ -495,7 +514,7 @@ int launch_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samp
 	const unsigned char* sc = (const unsigned char*)scene_blob;
 	if (strided) hipLaunchKernelGGL(k_sample_matrices, dim3(n_samples), dim3(32), 0, stream, frame_first, frame->stride, smat);
 	const uint32_t* sm = strided ? smat : nullptr;
-#define PT_GEN(STR, EXT) hipLaunchKernelGGL((k_generate<STR, EXT>), grid, block, lds, stream, f, sm, rng, sc, n_tris, qa, qb, hit)
+#define PT_GEN(STR, EXT) hipLaunchKernelGGL((k_generate<STR, EXT>), grid, block, lds, stream, f, sm, rng, sc, n_tris, qb, hit)
 	if (strided) { if (extend) PT_GEN(true, true); else PT_GEN(true, false); }
 	else { if (extend) PT_GEN(false, true); else PT_GEN(false, false); }
 #undef PT_GEN
@@ -644,7 +663,7 @@ int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samp
                     const uint32_t* rng, uint32_t* sample_matrices, const void* scene_blob, uint32_t n_triangles,
                     pt_queue out, void* hit, uint32_t capacity, uint32_t* counts, void* stream) {
 	if (int rc = check_frame(frame)) return rc;
-	if (!rng || !out.a || !out.b || !counts) return fail(PT_ERR_INVALID, "generate: null pointer");
+	if (!rng || !out.b || !counts) return fail(PT_ERR_INVALID, "generate: null pointer");
 	if (n_samples == 0 || n_samples > 65535) return fail(PT_ERR_INVALID, "generate: n_samples must be 1..65535");
 	if (frame->rng_mode == PT_RNG_SEQUENTIAL && n_samples != 1)
 		return fail(PT_ERR_INVALID, "generate: sequential RNG renders one sample per pass");
@@ -660,21 +679,28 @@ int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samp
 	if (hit && (!scene_blob || n_triangles > kShadeLdsMaxTris))
 		return fail(PT_ERR_INVALID, "generate: the fused extend needs a scene of at most 1536 triangles");
 	return launch_generate(frame, frame_first, n_samples, rng, sample_matrices, scene_blob, n_triangles,
-	                       (float4*)out.a, (float4*)out.b, (uint2*)hit, s);
+	                       (float4*)out.b, (uint2*)hit, s);
 }
 
-int pt_hip_extend(const void* scene_blob, uint32_t n_triangles, pt_queue in, const uint32_t* count, uint32_t capacity, void* hit, void* stream) {
-	if (!scene_blob || !in.a || !in.b || !count || !hit) return fail(PT_ERR_INVALID, "extend: null pointer");
+int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob, uint32_t n_triangles, pt_queue in,
+                  const uint32_t* count, uint32_t capacity, void* hit, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!scene_blob || !in.b || !count || !hit || (bounce > 0 && !in.a)) return fail(PT_ERR_INVALID, "extend: null pointer");
 	if (capacity == 0) return PT_OK;
-	hipLaunchKernelGGL(k_extend, dim3(grid_for(capacity)), dim3(kBlock), extend_lds_bytes(n_triangles), (hipStream_t)stream,
-	                   (const unsigned char*)scene_blob, n_triangles, (const float4*)in.a, (const float4*)in.b, count, capacity, (uint2*)hit);
+	FrameDev f = to_dev(*frame);
+	dim3 grid(grid_for(capacity)), block(kBlock);
+	size_t lds = extend_lds_bytes(n_triangles);
+	if (bounce == 0) hipLaunchKernelGGL(k_extend<true>, grid, block, lds, (hipStream_t)stream, f.origin, (const unsigned char*)scene_blob, n_triangles,
+	                                    (const float4*)in.a, (const float4*)in.b, count, capacity, (uint2*)hit);
+	else hipLaunchKernelGGL(k_extend<false>, grid, block, lds, (hipStream_t)stream, f.origin, (const unsigned char*)scene_blob, n_triangles,
+	                        (const float4*)in.a, (const float4*)in.b, count, capacity, (uint2*)hit);
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
 
 static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneInfo& si, uint32_t bounce,
                         pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
-                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, uint32_t* rng, hipStream_t s) {
+                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s) {
 	uint32_t last = (bounce + 1 >= f.depth) ? 1u : 0u;
 	bool lds = shade_scene_in_lds(si);
 	bool extend = hit_out != nullptr;
@@ -683,7 +709,7 @@ static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneIn
 	dim3 grid(grid_for(capacity)), block(kBlock);
 #define PT_SHADE(FIRST, LDS, EXT) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
 	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
-	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, rng)
+	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng)
 	if (bounce == 0) { if (extend) PT_SHADE(true, true, true); else if (lds) PT_SHADE(true, true, false); else PT_SHADE(true, false, false); }
 	else { if (extend) PT_SHADE(false, true, true); else if (lds) PT_SHADE(false, true, false); else PT_SHADE(false, false, false); }
 #undef PT_SHADE
@@ -693,25 +719,25 @@ static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneIn
 
 int pt_hip_shade(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, uint32_t bounce,
                  pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
-                 pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, uint32_t* rng, void* stream) {
+                 pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, void* stream) {
 	if (int rc = check_frame(frame)) return rc;
-	if (!scene_blob || !in.a || !in.b || !hit || !count_in || !out.a || !out.b || !out.c || !out.pid || !count_out || !radiance)
+	if (!scene_blob || !in.b || !hit || !count_in || !out.a || !out.b || !out.c || !out.pid || !count_out || !radiance || !lit)
 		return fail(PT_ERR_INVALID, "shade: null pointer");
-	if (bounce > 0 && (!in.c || !in.pid)) return fail(PT_ERR_INVALID, "shade: bounce > 0 needs in.c and in.pid");
+	if (bounce > 0 && (!in.a || !in.c || !in.pid)) return fail(PT_ERR_INVALID, "shade: bounce > 0 needs in.c and in.pid");
 	if (bounce >= frame->depth) return fail(PT_ERR_INVALID, "shade: bounce must be < depth");
 	if (frame->rng_mode == PT_RNG_SEQUENTIAL && !rng) return fail(PT_ERR_INVALID, "shade: sequential RNG needs rng");
 	if (capacity == 0) return PT_OK;
 	SceneInfo si{ n_triangles, n_materials };
-	return launch_shade(to_dev(*frame), scene_blob, si, bounce, in, hit, count_in, capacity, out, hit_out, count_out, radiance,
+	return launch_shade(to_dev(*frame), scene_blob, si, bounce, in, hit, count_in, capacity, out, hit_out, count_out, radiance, lit,
 	                    frame->rng_mode == PT_RNG_SEQUENTIAL ? rng : nullptr, (hipStream_t)stream);
 }
 
 int pt_hip_accumulate(uint32_t pixel_count, uint32_t mean_first, uint32_t n_samples,
-                      const void* radiance, void* mean, void* stream) {
+                      const void* radiance, const void* lit, void* mean, void* stream) {
 	if (pixel_count == 0 || n_samples == 0) return PT_OK;
-	if (!radiance || !mean) return fail(PT_ERR_INVALID, "accumulate: null pointer");
+	if (!radiance || !lit || !mean) return fail(PT_ERR_INVALID, "accumulate: null pointer");
 	hipLaunchKernelGGL(k_accumulate, dim3(grid_for(pixel_count)), dim3(kBlock), 0, (hipStream_t)stream,
-	                   pixel_count, mean_first, n_samples, (const float4*)radiance, (float4*)mean);
+	                   pixel_count, mean_first, n_samples, (const float4*)radiance, (const unsigned char*)lit, (float4*)mean);
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
@@ -753,20 +779,23 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 		uint32_t ns = std::min(samples_per_pass, n_samples - done);
 		uint32_t paths = ns * frame->pixel_count;
 		hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
-		if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.a[0], w.b[0],
+		if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0],
 		                             fuse ? w.hit[0] : nullptr, s)) return rc;
 		for (uint32_t b = 0; b < frame->depth; b++) {
 			int in = b & 1, out = in ^ 1;
-			if (!fuse)
-				hipLaunchKernelGGL(k_extend, dim3(G), dim3(kBlock), ext_lds, s, (const unsigned char*)scene_blob, si.n_tris,
+			if (!fuse) {
+				if (b == 0) hipLaunchKernelGGL(k_extend<true>, dim3(G), dim3(kBlock), ext_lds, s, f.origin, (const unsigned char*)scene_blob, si.n_tris,
 				                   (const float4*)w.a[in], (const float4*)w.b[in], (const uint32_t*)(w.counts + (size_t)b * G), (uint32_t)paths_cap, w.hit[in]);
+				else hipLaunchKernelGGL(k_extend<false>, dim3(G), dim3(kBlock), ext_lds, s, f.origin, (const unsigned char*)scene_blob, si.n_tris,
+				                   (const float4*)w.a[in], (const float4*)w.b[in], (const uint32_t*)(w.counts + (size_t)b * G), (uint32_t)paths_cap, w.hit[in]);
+			}
 			pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
 			if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
 			                          fuse ? w.hit[out] : nullptr, w.counts + (size_t)(b + 1) * G,
-			                          w.radiance, sequential ? rng : nullptr, s)) return rc;
+			                          w.radiance, w.lit, sequential ? rng : nullptr, s)) return rc;
 		}
 		hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
-		                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (float4*)mean);
+		                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
 		if (stats) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.counts, G, frame->depth, (unsigned long long*)stats);
 		HIP_TRY(hipGetLastError());
 	}

@@ -67,6 +67,7 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
     counts = DeviceBuffer(lib, (depth + 2) * G * 4)
     hits = [DeviceBuffer(lib, P * 8), DeviceBuffer(lib, P * 8)]
     radiance = DeviceBuffer(lib, P * 16).upload(np.full(P * 4, np.nan, dtype=np.float32))
+    lit = DeviceBuffer(lib, P).upload(np.full(P, 77, dtype=np.uint8))
     smat = DeviceBuffer(lib, n_samples * 32 * 4)
 
     # ---- generate (a4)
@@ -75,15 +76,13 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
     assert rc == 0, lib.pt_hip_last_error()
     sync(lib)
     paths = _oracle_paths(oracle, p, n_pix, pixel_first, n_samples, frame_first, rng0, strided, scene_o)
-    A = q[0]["a"].download(np.float32).reshape(P, 4)
-    B = q[0]["b"].download(np.float32).reshape(P, 4)
+    B = q[0]["b"].download(np.float32).reshape(P, 4)       # bounce-0 layout: {d.x, d.y, d.z, rng}
     cnt = counts.download(np.uint32)[:G]
     assert cnt.sum() == P
     assert sorted(queue_slots(cnt, G).tolist()) == list(range(P))
-    want_a = np.array([[x.origin.x, x.origin.y, x.origin.z, x.direction.x] for x in paths], dtype=np.float32)
-    want_b = np.array([[x.direction.y, x.direction.z, x.t, 0] for x in paths], dtype=np.float32)
-    assert np.array_equal(A.view(np.uint32), want_a.view(np.uint32))
+    want_b = np.array([[x.direction.x, x.direction.y, x.direction.z, 0] for x in paths], dtype=np.float32)
     assert np.array_equal(B[:, :3].view(np.uint32), want_b[:, :3].view(np.uint32))
+    assert all(x.origin.tuple() == (fr.origin.x, fr.origin.y, fr.origin.z, fr.origin.w) and x.t == np.finfo(np.float32).max for x in paths)
     assert np.array_equal(B[:, 3].view(np.uint32), np.array([x.rng for x in paths], dtype=np.uint32))
 
     # ---- bounces: extend (a5, a6) then shade (a7-a9)
@@ -95,7 +94,7 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
         cout = C.c_void_p(counts.ptr + (bounce + 1) * G * 4)
         hit = hits[i_in]
         if not fuse:
-            rc = lib.pt_hip_extend(scene_dev.ptr, len(T), Q[i_in], cin, P, hit.ptr, None)
+            rc = lib.pt_hip_extend(C.byref(fr), bounce, scene_dev.ptr, len(T), Q[i_in], cin, P, hit.ptr, None)
             assert rc == 0, lib.pt_hip_last_error()
         sync(lib)
         cnt = counts.download(np.uint32)[bounce * G:(bounce + 1) * G]
@@ -111,7 +110,7 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
             want_tri = 0xFFFFFFFF if path.hit_tri < 0 else path.hit_tri
             assert (H[slot, 0], H[slot, 1]) == (want_t, want_tri), (bounce, int(pid))
         rc = lib.pt_hip_shade(C.byref(fr), scene_dev.ptr, len(T), len(M), bounce, Q[i_in], hit.ptr, cin, P, Q[i_out],
-                              hits[i_out].ptr if fuse else None, cout, radiance.ptr, rng.ptr if not strided else None, None)
+                              hits[i_out].ptr if fuse else None, cout, radiance.ptr, lit.ptr, rng.ptr if not strided else None, None)
         assert rc == 0, lib.pt_hip_last_error()
         sync(lib)
         n_diffuse = 0
@@ -144,10 +143,14 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
         if not alive:
             break
     # every path wrote its radiance exactly once
+    Lt = lit.download(np.uint8)
+    assert set(np.unique(Lt).tolist()) <= {0, 1}              # every path set its flag exactly once
     R = radiance.download(np.float32).reshape(P, 4)
+    R[Lt == 0] = np.array([0, 0, 0, 1], dtype=np.float32)     # unlit samples are (0,0,0,1) by definition
     assert not np.isnan(R).any()
     want_r = np.array([paths[pid].frame.tuple() for pid in range(P)], dtype=np.float32)
     assert np.array_equal(R.view(np.uint32), want_r.view(np.uint32))
+    assert np.array_equal(Lt == 1, np.array([paths[pid].frame.tuple() != (0.0, 0.0, 0.0, 1.0) for pid in range(P)]))
     if not strided:
         got_rng = rng.download(np.uint32)
         assert np.array_equal(got_rng, np.array([paths[pid].rng for pid in range(P)], dtype=np.uint32))
@@ -156,7 +159,7 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
     mean0 = np.random.default_rng(1).random((n_pix, 4), dtype=np.float32)
     mean = DeviceBuffer(lib, n_pix * 16).upload(mean0)
     mean_first = 7
-    assert lib.pt_hip_accumulate(n_pix, mean_first, n_samples, radiance.ptr, mean.ptr, None) == 0
+    assert lib.pt_hip_accumulate(n_pix, mean_first, n_samples, radiance.ptr, lit.ptr, mean.ptr, None) == 0
     sync(lib)
     got = mean.download(np.float32).reshape(n_pix, 4)
     want = mean0.copy()
