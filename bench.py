@@ -40,15 +40,6 @@ P_LIGHT = 0.0473
 BYTES_PER_RAY = (276.0 + 44.0 * P_LIGHT) / 2.0
 
 
-def device_tensor(ptr, n_floats, torch):
-    """A torch view of plugin-owned device memory (no copy), via __cuda_array_interface__."""
-    class _Wrap:
-        pass
-    w = _Wrap()
-    w.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(w, device="cuda")
-
-
 def cpu_baseline(spp):
     """The oracle (kind 'port': our C restatement of the reference path) on the host cores."""
     from oracle import pt_oracle_py as po
@@ -78,6 +69,7 @@ def main():
     ap.add_argument("--engine", choices=["fused", "wavefront"], default="fused")
     ap.add_argument("--samples-per-pass", type=int, default=16, help="wavefront strided batching")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange even with one rank (self-test of the N>1 path)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     args = ap.parse_args()
@@ -92,8 +84,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w, h = args.width, args.height
@@ -101,7 +95,7 @@ def main():
     engine = pt.PT_ENGINE_FUSED if args.engine == "fused" else pt.PT_ENGINE_WAVEFRONT
     total_steps = args.warmup + args.steps
     tracer = pt.PathTracer(w, h, device=local_rank)
-    if world > 1:
+    if dist:
         # rank r owns samples [r*S, (r+1)*S) of the frame, S = all its steps' samples
         tracer.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, depth=DEPTH,
                            samples_per_pass=args.samples_per_pass, sample_offset=rank * total_steps * SPP_PER_STEP)   # = sample_split.shard_samples
@@ -112,23 +106,27 @@ def main():
     lib = pt.load_library()
 
     combine = None
-    if world > 1:
+    if dist:
         assert n_pix % world == 0, "image must split evenly over the ranks"
         slice_floats = n_pix * 4 // world
-        mean_t = device_tensor(tracer.device_mean(), n_pix * 4, torch)
+        # the exchange works on a snapshot of the running mean, so the next step's samples can render
+        # (plugin stream) while RCCL moves the previous step's image (torch/RCCL streams)
+        snapshot = torch.empty(n_pix * 4, device="cuda", dtype=torch.float32)
         gathered = torch.empty(world * slice_floats, device="cuda", dtype=torch.float32)   # shard-major slices
         image = torch.empty(n_pix * 4, device="cuda", dtype=torch.float32)
 
         from pathtracer_amd import sample_split
 
-        def combine_slices(stacked, shards, n_pix, out_slice):
-            rc = lib.pt_hip_combine_shards(stacked.data_ptr(), shards, n_pix, out_slice.data_ptr(),
+        def combine_slices(stacked, shards, n_pix_slice, out_slice):
+            rc = lib.pt_hip_combine_shards(stacked.data_ptr(), shards, n_pix_slice, out_slice.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.pt_hip_last_error()
 
         def combine():
-            # all_to_all of image slices -> fixed-order tree on this rank's slice -> all_gather
-            sample_split.exchange_and_combine(mean_t, dist, combine_slices, out=image, scratch=gathered)
+            torch.cuda.current_stream().synchronize()          # the previous exchange is done with `snapshot`
+            tracer.copy_mean(snapshot.data_ptr(), n_pix * 4)
+            # all_to_all of image slices -> fixed-order tree on this rank's slice -> all_gather; enqueued, not awaited
+            sample_split.exchange_and_combine(snapshot, dist, combine_slices, out=image, scratch=gathered)
 
     def step():
         tracer.render(SPP_PER_STEP)                           # blocks until the samples are in the mean
@@ -187,8 +185,8 @@ def main():
             "spp_per_s": round(SPP_PER_STEP * world * args.steps / dt, 1),
             "config": {"workload": f"reference default scene {w}x{h}, {SPP_PER_STEP} spp per step per GPU, depth {DEPTH}, seed 1337 "
                                    f"(BASELINE.json configs[1])",
-                       "engine": args.engine, "rng": "sequential" if (world == 1 and args.engine == "fused") else "strided/35",
-                       "parallelism": "single GPU" if world == 1 else f"sample split x{world}, fixed-order combine over RCCL"},
+                       "engine": args.engine, "rng": "sequential" if (not dist and args.engine == "fused") else "strided/35",
+                       "parallelism": "single GPU" if not dist else f"sample split x{world}, fixed-order combine over RCCL (all_to_all + all_gather), overlapped with the next step"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_fused" if args.engine == "fused" else "wavefront pass (generate+extend+shade+accumulate)",

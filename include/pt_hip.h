@@ -85,6 +85,7 @@ int pt_hip_malloc(void** device_ptr, size_t bytes);
 int pt_hip_free(void* device_ptr);
 int pt_hip_memcpy_h2d(void* device_dst, const void* host_src, size_t bytes, void* stream);
 int pt_hip_memcpy_d2h(void* host_dst, const void* device_src, size_t bytes, void* stream);
+int pt_hip_memcpy_d2d(void* device_dst, const void* device_src, size_t bytes, void* stream);   /* asynchronous */
 int pt_hip_memset(void* device_dst, int byte_value, size_t bytes, void* stream);
 int pt_hip_fill_f32(float* device_dst, float value, size_t count, void* stream);
 int pt_hip_stream_create(void** stream);

@@ -91,6 +91,9 @@ int pt_render(pt_handle* h, uint32_t spp);
 int pt_readback(pt_handle* h, float* rgba, size_t n_floats);
 /* Per-pixel RNG streams (SEQUENTIAL) or sample-0 states (STRIDED), n = pixel_count. */
 int pt_readback_rng(pt_handle* h, uint32_t* states, size_t n);
+/* Device-to-device copy of the running mean into caller-owned device memory (n_floats = 4 * pixel_count);
+ * returns when the copy is complete.  The snapshot collectives work on while the next samples render. */
+int pt_copy_mean(pt_handle* h, void* device_dst, size_t n_floats);
 /* Device address of the running mean (float4 x pixel_count), for collectives and zero-copy. */
 void* pt_device_mean(pt_handle* h);
 int pt_get_stats(pt_handle* h, pt_stats* out);

@@ -103,6 +103,7 @@ SYMBOLS = {
     "pt_render": (C.c_int, [_VP, _U32]),
     "pt_readback": (C.c_int, [_VP, _VP, _SZ]),
     "pt_readback_rng": (C.c_int, [_VP, _VP, _SZ]),
+    "pt_copy_mean": (C.c_int, [_VP, _VP, _SZ]),
     "pt_device_mean": (_VP, [_VP]),
     "pt_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
     "pt_get_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), _U32P, _U32P]),
@@ -114,6 +115,7 @@ SYMBOLS = {
     "pt_hip_free": (C.c_int, [_VP]),
     "pt_hip_memcpy_h2d": (C.c_int, [_VP, _VP, _SZ, _VP]),
     "pt_hip_memcpy_d2h": (C.c_int, [_VP, _VP, _SZ, _VP]),
+    "pt_hip_memcpy_d2d": (C.c_int, [_VP, _VP, _SZ, _VP]),
     "pt_hip_memset": (C.c_int, [_VP, C.c_int, _SZ, _VP]),
     "pt_hip_fill_f32": (C.c_int, [_VP, C.c_float, _SZ, _VP]),
     "pt_hip_stream_create": (C.c_int, [C.POINTER(_VP)]),
@@ -278,6 +280,10 @@ class PathTracer:
         out = np.empty(count, dtype=np.uint32)
         _check(self._lib.pt_readback_rng(self._h, out.ctypes.data_as(C.c_void_p), out.size), self._lib, "pt_readback_rng")
         return out
+
+    def copy_mean(self, device_ptr: int, n_floats: int) -> None:
+        """Snapshot of the running mean into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
+        _check(self._lib.pt_copy_mean(self._h, C.c_void_p(int(device_ptr)), int(n_floats)), self._lib, "pt_copy_mean")
 
     def device_mean(self) -> int:
         return int(self._lib.pt_device_mean(self._h) or 0)

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 			float best = FLT_MAX;
 			float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
+			uint32_t draws = 2;                      // this sample's RNG draws: 2 + 33 per diffuse bounce
 			for (uint32_t b = 0; b < f.depth; b++) {
 				n_rays++;
 				uint32_t tri = kNoHit;
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 				if (type == PT_MAT_DIFFUSE) {
 					shade_diffuse(Vec3{ r2.y, r2.z, r2.w }, color, best, s_jump, o, d, step, rng);
 					n_diffuse++;
+					draws += 33;
 				} else {
 					if (type == PT_MAT_EMISSIVE)
 						frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };
@@ -430,7 +432,12 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 				}
 			}
 			m = running_mean(frame, m, mean_first + s);
-			if (STRIDED) { start = mat_apply(per_sample.cols, start); rng = start; }
+			if (STRIDED) {
+				// next sample starts at step^stride(start); when this sample drew exactly `stride`
+				// numbers (always, at stride 35 on the default scene) that is the state we are in
+				if (draws != f.stride) rng = mat_apply(per_sample.cols, start);
+				start = rng;
+			}
 		}
 		mean_io[li] = m;
 		if (!STRIDED) rng_io[li] = rng;
@@ -556,6 +563,12 @@ int pt_hip_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream) {
 	if (!d || !h) return fail(PT_ERR_INVALID, "memcpy_d2h: null pointer");
 	HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
 	HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+	return PT_OK;
+}
+int pt_hip_memcpy_d2d(void* d, const void* src, size_t bytes, void* stream) {
+	if (bytes == 0) return PT_OK;
+	if (!d || !src) return fail(PT_ERR_INVALID, "memcpy_d2d: null pointer");
+	HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
 	return PT_OK;
 }
 int pt_hip_memset(void* d, int byte_value, size_t bytes, void* stream) {

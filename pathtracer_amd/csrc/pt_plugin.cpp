@@ -232,6 +232,15 @@ public:
 		PT_TRY(pt_hip_memcpy_d2h(states, _dev.rng, n * sizeof(uint32_t), _stream));
 		return PT_OK;
 	}
+	int CopyMean(void* device_dst, size_t n_floats) {
+		if (_error) return _error;
+		if (!device_dst) return plugin_fail(PT_ERR_INVALID, "copy_mean: null pointer");
+		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "copy_mean: n_floats must be 4 * pixel_count");
+		if (_drawState == Drawing) FinalizeDrawing();
+		PT_TRY(pt_hip_memcpy_d2d(device_dst, _dev.mean, n_floats * sizeof(float), _stream));
+		PT_TRY(pt_hip_stream_synchronize(_stream));
+		return PT_OK;
+	}
 	void* DeviceMean() { if (_drawState == Drawing) FinalizeDrawing(); return _dev.mean; }
 
 	int Stats(pt_stats* out) {
@@ -387,6 +396,7 @@ int pt_set_scene(pt_handle* h, const pt_vertex* v, uint32_t nv, const pt_triangl
 int pt_render(pt_handle* h, uint32_t spp) { PT_HANDLE(h); return tracer->Render(spp); }
 int pt_readback(pt_handle* h, float* rgba, size_t n_floats) { PT_HANDLE(h); return tracer->Readback(rgba, n_floats); }
 int pt_readback_rng(pt_handle* h, uint32_t* states, size_t n) { PT_HANDLE(h); return tracer->ReadbackRng(states, n); }
+int pt_copy_mean(pt_handle* h, void* device_dst, size_t n_floats) { PT_HANDLE(h); return tracer->CopyMean(device_dst, n_floats); }
 void* pt_device_mean(pt_handle* h) { return h ? as_tracer(h)->DeviceMean() : nullptr; }
 int pt_get_stats(pt_handle* h, pt_stats* out) {
 	PT_HANDLE(h);
