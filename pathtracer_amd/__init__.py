@@ -125,12 +125,13 @@ SYMBOLS = {
     "pt_hip_event_destroy": (C.c_int, [_VP]),
     "pt_hip_event_record": (C.c_int, [_VP, _VP]),
     "pt_hip_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
+    "pt_hip_set_bvh_threshold": (C.c_int, [_U32]),
     "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),
     "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
     "pt_hip_rng_seed": (C.c_int, [_FRAMEP, _VP, _VP]),
     "pt_hip_queue_blocks": (_U32, [_U32]),
     "pt_hip_generate": (C.c_int, [_FRAMEP, _U32, _U32, _VP, _VP, _VP, _U32, Queue, _VP, _U32, _VP, _VP]),
-    "pt_hip_extend": (C.c_int, [_FRAMEP, _U32, _VP, _U32, Queue, _VP, _U32, _VP, _VP]),
+    "pt_hip_extend": (C.c_int, [_FRAMEP, _U32, _VP, _U32, _U32, Queue, _VP, _U32, _VP, _VP]),
     "pt_hip_shade": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, Queue, _VP, _VP, _U32, Queue, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pt_hip_accumulate": (C.c_int, [_U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "pt_hip_wavefront_workspace_bytes": (_SZ, [_U32, _U32, _U32]),

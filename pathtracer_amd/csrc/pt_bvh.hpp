@@ -1,0 +1,147 @@
+// pt_bvh.hpp -- bounding-volume hierarchy for the extend stage (the reference is
+// brute force, kernels.cu:62-68).  The BVH is only a CULLING structure: every triangle that reaches
+// a leaf goes through the same ray_triangle() as the brute-force loop, and hits are ranked by
+// (t, original triangle index), so the result is the brute-force result bit for bit -- provided no
+// box test ever culls a triangle the fp32 Moeller-Trumbore test would accept.
+//
+// Why that needs care: ray_triangle accepts when the COMPUTED u, v satisfy 0<=u, 0<=v, u+v<=1, and
+// those carry rounding error amplified by f = 1/det.  The reference's own culling gives the handle:
+// an accepted hit has det >= EPSILON (Functions.cuh:72).  With eps = 2^-24,
+//     |du| * |e0|  <~  c * eps * |d| * |e0||e1| * (|s| + |e0|) / det   <=  c * eps * |e0||e1| * S / EPSILON
+// (|d| <= 1 for every ray this tracer makes, S bounds |origin - vertex| + edge length), likewise for v
+// and for t.  So the true ray/plane intersection of an accepted hit lies within
+//     delta_i = kappa_i * S,   kappa_i = 24 * eps * |e0||e1| / EPSILON        (c = 24: 3x head-room)
+// of triangle i.  Each child box stores the max kappa of its subtree; the traversal inflates the box
+// by kappa * S + a relative slack for its own arithmetic, and widens the ray interval by the root's
+// delta.  Small triangles (the 10^4..10^5-triangle scenes this is for) get small inflations
+// (|e0||e1| = 2e-4 -> delta = 3e-4 * S); large ones get large boxes, which only costs time.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "pt_hip.h"
+
+namespace ptbvh {
+
+constexpr uint32_t kLeafSize = 4;
+constexpr float kEps32 = 5.9604645e-8f;            // 2^-24
+constexpr float kKappaScale = 24.0f * kEps32 / 0.000001f;
+
+// 64 bytes: the two children's boxes live in the parent.
+struct Node {
+	float lo0[3], hi0[3];
+	float lo1[3], hi1[3];
+	int32_t child0, child1;     // >= 0: node index; < 0: leaf, ~child = (first << 3) | (count - 1)
+	float kappa0, kappa1;       // max kappa of the child's subtree
+};
+static_assert(sizeof(Node) == 64, "BVH node is 4 float4");
+
+// 64 bytes: what the leaf test needs, in BVH order.  {v0.xyz, e0.x} {e0.yz, e1.xy} {e1.z, orig index bits, 0, 0} {pad}
+struct LeafTri { float f[16]; };
+
+struct Built {
+	std::vector<Node> nodes;
+	std::vector<LeafTri> tris;
+	float center[3] = { 0, 0, 0 };
+	float radius = 0.0f;
+	float kappa_root = 0.0f;
+};
+
+struct Prim { float lo[3], hi[3], c[3]; float kappa; uint32_t idx; };
+
+inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+inline void bounds_of(const std::vector<Prim>& p, uint32_t a, uint32_t b, float lo[3], float hi[3], float& kappa) {
+	for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+	kappa = 0.0f;
+	for (uint32_t i = a; i < b; i++) {
+		for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[i].lo[k]); hi[k] = std::max(hi[k], p[i].hi[k]); }
+		kappa = std::max(kappa, p[i].kappa);
+	}
+}
+
+// Median split on the widest centroid axis; leaves of up to kLeafSize triangles.
+inline int32_t build_range(std::vector<Prim>& p, uint32_t a, uint32_t b, Built& out) {
+	if (b - a <= kLeafSize) return encode_leaf(a, b - a);
+	float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (uint32_t i = a; i < b; i++)
+		for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], p[i].c[k]); chi[k] = std::max(chi[k], p[i].c[k]); }
+	int axis = 0;
+	for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+	uint32_t mid = (a + b) / 2;
+	std::nth_element(p.begin() + a, p.begin() + mid, p.begin() + b,
+	                 [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
+	uint32_t me = (uint32_t)out.nodes.size();
+	out.nodes.emplace_back();
+	Node n{};
+	bounds_of(p, a, mid, n.lo0, n.hi0, n.kappa0);
+	bounds_of(p, mid, b, n.lo1, n.hi1, n.kappa1);
+	n.child0 = build_range(p, a, mid, out);
+	n.child1 = build_range(p, mid, b, out);
+	out.nodes[me] = n;
+	return (int32_t)me;
+}
+
+inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris) {
+	Built out;
+	std::vector<Prim> prims(n_tris);
+	float slo[3] = { INFINITY, INFINITY, INFINITY }, shi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (uint32_t i = 0; i < n_tris; i++) {
+		const pt_float4* P[3] = { &v[t[i].vertexIdx0].position, &v[t[i].vertexIdx1].position, &v[t[i].vertexIdx2].position };
+		Prim& pr = prims[i];
+		for (int k = 0; k < 3; k++) { pr.lo[k] = INFINITY; pr.hi[k] = -INFINITY; }
+		for (int c = 0; c < 3; c++) {
+			const float xyz[3] = { P[c]->x, P[c]->y, P[c]->z };
+			for (int k = 0; k < 3; k++) { pr.lo[k] = std::min(pr.lo[k], xyz[k]); pr.hi[k] = std::max(pr.hi[k], xyz[k]); }
+		}
+		for (int k = 0; k < 3; k++) {
+			pr.c[k] = 0.5f * (pr.lo[k] + pr.hi[k]);
+			slo[k] = std::min(slo[k], pr.lo[k]); shi[k] = std::max(shi[k], pr.hi[k]);
+		}
+		float e0[3] = { P[1]->x - P[0]->x, P[1]->y - P[0]->y, P[1]->z - P[0]->z };
+		float e1[3] = { P[2]->x - P[0]->x, P[2]->y - P[0]->y, P[2]->z - P[0]->z };
+		float l0 = std::sqrt(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2]);
+		float l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+		pr.kappa = kKappaScale * l0 * l1;
+		pr.idx = i;
+	}
+	float r2 = 0.0f;
+	for (int k = 0; k < 3; k++) {
+		out.center[k] = n_tris ? 0.5f * (slo[k] + shi[k]) : 0.0f;
+		float h = n_tris ? 0.5f * (shi[k] - slo[k]) : 0.0f;
+		r2 += h * h;
+	}
+	out.radius = std::sqrt(r2);
+	out.nodes.reserve(n_tris);
+	if (n_tris == 0) return out;
+	int32_t root = build_range(prims, 0, n_tris, out);
+	if (root < 0) {                                   // a single leaf: wrap it so the root is always node 0
+		Node n{};
+		bounds_of(prims, 0, n_tris, n.lo0, n.hi0, n.kappa0);
+		n.child0 = root;
+		for (int k = 0; k < 3; k++) { n.lo1[k] = 1e30f; n.hi1[k] = 1e30f; }   // far-away point box: (almost) never entered; entering it re-tests one triangle, which is harmless
+		n.child1 = encode_leaf(0, 1);
+		n.kappa1 = 0.0f;
+		out.nodes.push_back(n);
+	}
+	out.kappa_root = std::max(out.nodes[0].kappa0, out.nodes[0].kappa1);
+	out.tris.resize(n_tris);
+	for (uint32_t k = 0; k < n_tris; k++) {
+		uint32_t i = prims[k].idx;
+		const pt_float4 &v0 = v[t[i].vertexIdx0].position, &v1 = v[t[i].vertexIdx1].position, &v2 = v[t[i].vertexIdx2].position;
+		float* f = out.tris[k].f;
+		std::memset(f, 0, sizeof(LeafTri));
+		f[0] = v0.x; f[1] = v0.y; f[2] = v0.z;
+		f[3] = v1.x - v0.x; f[4] = v1.y - v0.y; f[5] = v1.z - v0.z;     // the reference's edge0 (Functions.cuh:65)
+		f[6] = v2.x - v0.x; f[7] = v2.y - v0.y; f[8] = v2.z - v0.z;     // edge1 (:66)
+		std::memcpy(&f[9], &i, 4);
+	}
+	return out;
+}
+
+} // namespace ptbvh

@@ -98,10 +98,23 @@ struct TriRec { float4 r0, r1, r2, r3; };
 // One packed material: {type bits,0,0,0} {color}
 struct MatRec { float4 head, color; };
 
-struct SceneHeader {
+struct SceneHeader {                                   // 64 bytes
 	uint32_t n_tris, n_mats, tri_offset, mat_offset;   // offsets in bytes from the blob start
-	uint32_t magic, blob_bytes, _pad[2];
+	uint32_t magic, blob_bytes, n_nodes, bvh_offset;   // n_nodes = 0: no BVH (small scene, brute force)
+	uint32_t leaf_offset;
+	float    center[3], radius;                        // bounding sphere of the vertices
+	float    kappa_root;                               // see pt_bvh.hpp
+	uint32_t _pad[2];
 };
+static_assert(sizeof(SceneHeader) == 64, "SceneHeader is 64 bytes");
+
+// Scenes above this many triangles carry a BVH and are traversed with it (pt_bvh.hpp).
+constexpr uint32_t kBvhMinTris = 64;
+constexpr int kBvhStackDepth = 24;                     // per-lane stack of deferred nodes, in LDS
+
+__host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
+	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
+}
 constexpr uint32_t kSceneMagic = 0x50544853u;  // "PTHS"
 
 // Moeller-Trumbore with culling, Functions.cuh:56-89.  Returns true and t unless the reference
@@ -130,6 +143,94 @@ __device__ __forceinline__ void intersect_range(const float4* __restrict__ tris,
 		float t;
 		if (ray_triangle(o, d, Vec3{ r0.x, r0.y, r0.z }, Vec3{ r0.w, r1.x, r1.y }, Vec3{ r1.z, r1.w, r2.x }, t)) {
 			if (t > kEpsilon && t < best_t) { best_t = t; hit_tri = first + k; }   // :64
+		}
+	}
+}
+
+// ---- BVH traversal (pt_bvh.hpp): same answer as intersect_range over all triangles ----
+struct BvhView {
+	const float4* nodes;     // 4 float4 per node
+	const float4* leaves;    // 4 float4 per triangle, BVH order
+	float s_bound;           // bound on |ray origin - vertex| + edge length for this launch
+	float slack;             // absolute slack of the box arithmetic
+	float delta_root;        // kappa_root * s_bound: how far outside its triangle an accepted hit can be
+};
+
+__device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
+	const SceneHeader* hdr = reinterpret_cast<const SceneHeader*>(scene);
+	uint32_t off = bvh_offset_of(n_tris, n_mats);
+	BvhView v;
+	v.nodes = reinterpret_cast<const float4*>(scene + off);
+	v.leaves = reinterpret_cast<const float4*>(scene + off + (size_t)n_tris * 64u);
+	float dx = origin.x - hdr->center[0], dy = origin.y - hdr->center[1], dz = origin.z - hdr->center[2];
+	// every ray starts at the camera or on a triangle: |origin - vertex| <= |camera - centre| + 2 radius; edges <= 2 radius
+	v.s_bound = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) + 4.0f * hdr->radius;
+	float cmag = fabsf(hdr->center[0]) + fabsf(hdr->center[1]) + fabsf(hdr->center[2]) + hdr->radius;
+	v.slack = 2e-6f * (cmag + v.s_bound);
+	v.delta_root = hdr->kappa_root * v.s_bound + v.slack;
+	return v;
+}
+
+// slab test of one child box inflated by `infl`; [tlo, thi] is the (widened) ray interval
+__device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, float hy, float hz, float infl,
+                                        Vec3 o, Vec3 inv, float tlo, float thi, float& tnear) {
+	float ax = (lx - infl - o.x) * inv.x, bx = (hx + infl - o.x) * inv.x;
+	float ay = (ly - infl - o.y) * inv.y, by = (hy + infl - o.y) * inv.y;
+	float az = (lz - infl - o.z) * inv.z, bz = (hz + infl - o.z) * inv.z;
+	float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tlo));
+	float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), thi));
+	tnear = t0;
+	// widen by a relative hair for the products' own rounding (the absolute part is in infl)
+	return t0 <= t1 + 1e-5f * fabsf(t1);
+}
+
+__device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint32_t code, Vec3 o, Vec3 d,
+                                         float& best_t, uint32_t& hit_tri) {
+	uint32_t first = code >> 3, count = (code & 7u) + 1u;
+	for (uint32_t k = 0; k < count; k++) {
+		const float4* rec = leaves + (size_t)(first + k) * 4;
+		float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+		float t;
+		if (ray_triangle(o, d, Vec3{ r0.x, r0.y, r0.z }, Vec3{ r0.w, r1.x, r1.y }, Vec3{ r1.z, r1.w, r2.x }, t)) {
+			uint32_t idx = __float_as_uint(r2.y);
+			// kernels.cu:64 over ALL triangles in index order == min over (t, index): ties go to the lower index
+			if (t > kEpsilon && (t < best_t || (t == best_t && hit_tri != kNoHit && idx < hit_tri))) { best_t = t; hit_tri = idx; }
+		}
+	}
+}
+
+// `stack` points at this lane's column of an LDS array laid out [level][256 lanes].
+__device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
+                                              uint32_t* stack) {
+	// a zero component would make 0 * inf = NaN in the slabs; a direction error of 1e-20 is far inside the inflation
+	Vec3 dd{ fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x, fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y,
+	         fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z };
+	Vec3 inv{ 1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z };
+	float dlen = __builtin_sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
+	float dt = 1.01f * bv.delta_root / dlen;            // the root delta in ray-parameter units
+	float tlo = -dt;
+	uint32_t cur = 0;
+	int sp = 0;
+	for (;;) {
+		const float4* n = bv.nodes + (size_t)cur * 4;
+		float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+		int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
+		float thi = best_t + dt + 1e-6f * best_t;
+		float tn0, tn1;
+		bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * bv.s_bound + bv.slack, o, inv, tlo, thi, tn0);
+		bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * bv.s_bound + bv.slack, o, inv, tlo, thi, tn1);
+		if (h0 && c0 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c0, o, d, best_t, hit_tri); h0 = false; }
+		if (h1 && c1 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c1, o, d, best_t, hit_tri); h1 = false; }
+		if (h0 && h1) {
+			bool first0 = tn0 <= tn1;
+			if (sp < kBvhStackDepth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }
+			cur = (uint32_t)(first0 ? c0 : c1);
+		} else if (h0) cur = (uint32_t)c0;
+		else if (h1) cur = (uint32_t)c1;
+		else {
+			if (sp == 0) break;
+			sp--;
+			cur = stack[sp * 256];
 		}
 	}
 }

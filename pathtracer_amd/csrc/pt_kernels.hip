@@ -22,6 +22,7 @@
 
 #include "pt_hip.h"
 #include "pt_device.hpp"
+#include "pt_bvh.hpp"
 
 #pragma clang fp contract(off)
 
@@ -104,6 +105,7 @@ void host_jump_matrix(uint64_t k, uint32_t cols[32]) {
 }
 
 struct JumpMat { uint32_t cols[32]; };
+struct SceneInfo { uint32_t n_tris, n_mats; };
 
 // ------------------------------------------------------------------------------- kernels
 
@@ -187,8 +189,8 @@ __global__ void k_set_count(uint32_t* __restrict__ counts, uint32_t G, uint32_t 
 }
 
 // a5+a6. Scene triangles staged in LDS; one thread per queue entry, block-uniform loops.
-template <bool FIRST>
-__global__ __launch_bounds__(kBlock) void k_extend(float4 origin, const unsigned char* __restrict__ scene, uint32_t n_tris,
+template <bool FIRST, bool BVH>
+__global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                    const float4* __restrict__ qa, const float4* __restrict__ qb,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t capacity,
                                                    uint2* __restrict__ hit) {
@@ -196,7 +198,10 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, const unsigned
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const uint32_t G = gridDim.x;
 	const uint32_t count = count_ptr[blockIdx.x];
-	const bool single = n_tris <= kLdsTriChunk;
+	__shared__ uint32_t s_stack[BVH ? kBvhStackDepth * kBlock : 1];
+	BvhView bv{};
+	if (BVH) bv = make_bvh_view(scene, n_tris, n_mats, camera);
+	const bool single = !BVH && n_tris <= kLdsTriChunk;
 	if (single) {
 		for (uint32_t k = threadIdx.x; k < n_tris * 4; k += kBlock) s_tris[k] = g_tris[k];
 		__syncthreads();
@@ -210,7 +215,9 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, const unsigned
 		Vec3 d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
 		float best = FIRST ? FLT_MAX : b.z;
 		uint32_t tri = kNoHit;
-		if (single) {
+		if (BVH) {
+			if (active) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+		} else if (single) {
 			if (active) intersect_range(s_tris, 0, n_tris, o, d, best, tri);
 		} else {
 			for (uint32_t c0 = 0; c0 < n_tris; c0 += kLdsTriChunk) {
@@ -379,15 +386,21 @@ __global__ __launch_bounds__(kBlock) void k_fill_f32(float* __restrict__ dst, fl
 }
 
 // Fused engine: one lane per pixel, samples in order, all path state in registers.
-template <bool STRIDED, bool SCENE_LDS>
+// SCENE: 0 = brute force, wave-uniform reads through the scalar cache; 1 = brute force from LDS; 2 = BVH
+template <bool STRIDED, int SCENE>
 __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
                                                   uint32_t mean_first, uint32_t n_samples,
                                                   uint32_t* __restrict__ rng_io, float4* __restrict__ mean_io,
                                                   unsigned long long* __restrict__ stats) {
+	constexpr bool SCENE_LDS = SCENE == 1;
+	constexpr bool BVH = SCENE == 2;
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
+	__shared__ uint32_t s_stack[BVH ? kBvhStackDepth * kBlock : 1];
 	stage_jump31(s_jump);
+	BvhView bv{};
+	if (BVH) bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
 	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const float4* mats = tris + (size_t)n_tris * 4;
 	if (SCENE_LDS) {
@@ -415,7 +428,8 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 			for (uint32_t b = 0; b < f.depth; b++) {
 				n_rays++;
 				uint32_t tri = kNoHit;
-				intersect_range(tris, 0, n_tris, o, d, best, tri);
+				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+				else intersect_range(tris, 0, n_tris, o, d, best, tri);
 				if (tri == kNoHit) break;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
 				uint32_t mi = __float_as_uint(r3.x);
@@ -476,7 +490,6 @@ __global__ __launch_bounds__(kBlock) void k_combine(const float4* __restrict__ s
 	}
 }
 
-struct SceneInfo { uint32_t n_tris, n_mats; };
 
 
 size_t extend_lds_bytes(uint32_t n_tris) { return (size_t)std::min(n_tris, kLdsTriChunk) * sizeof(TriRec); }
@@ -509,6 +522,21 @@ size_t carve(Workspace* w, unsigned char* base, size_t paths, uint32_t samples_p
 	w->counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
 	w->smat = (uint32_t*)take((size_t)samples_per_pass * 32 * 4);
 	return off;
+}
+
+uint32_t g_bvh_min_tris = kBvhMinTris;       // pt_hip_set_bvh_threshold
+bool scene_has_bvh(const SceneInfo& s) { return s.n_tris > g_bvh_min_tris; }
+
+void launch_extend(const FrameDev& f, uint32_t bounce, const void* scene_blob, const SceneInfo& si, const float4* qa, const float4* qb,
+                   const uint32_t* counts, uint32_t capacity, uint2* hit, hipStream_t s) {
+	dim3 grid(grid_for(capacity)), block(kBlock);
+	const unsigned char* sc = (const unsigned char*)scene_blob;
+	bool bvh = scene_has_bvh(si);
+	size_t lds = bvh ? 0 : extend_lds_bytes(si.n_tris);
+#define PT_EXT(FIRST, BVH) hipLaunchKernelGGL((k_extend<FIRST, BVH>), grid, block, lds, s, f.origin, f.origin, sc, si.n_tris, si.n_mats, qa, qb, counts, capacity, hit)
+	if (bounce == 0) { if (bvh) PT_EXT(true, true); else PT_EXT(true, false); }
+	else { if (bvh) PT_EXT(false, true); else PT_EXT(false, false); }
+#undef PT_EXT
 }
 
 int launch_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samples, const uint32_t* rng,
@@ -613,8 +641,13 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
 	return PT_OK;
 }
 
+int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_triangles; return PT_OK; }
+
 size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
-	return sizeof(SceneHeader) + (size_t)n_triangles * sizeof(TriRec) + (size_t)n_materials * sizeof(MatRec);
+	size_t n = bvh_offset_of(n_triangles, n_materials);
+	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes and n_triangles leaf records, 64 B each
+	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * 128u;
+	return n;
 }
 
 int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
@@ -626,20 +659,40 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 	if (blob_bytes < pt_hip_scene_blob_bytes(n_triangles, n_materials)) return fail(PT_ERR_NOMEM, "scene_pack: blob too small");
 	if (n_triangles > (1u << 26)) return fail(PT_ERR_LIMIT, "scene_pack: more than 2^26 triangles");
 	unsigned char* base = (unsigned char*)host_blob;
-	SceneHeader hdr{};
-	hdr.n_tris = n_triangles; hdr.n_mats = n_materials;
-	hdr.tri_offset = (uint32_t)sizeof(SceneHeader);
-	hdr.mat_offset = hdr.tri_offset + n_triangles * (uint32_t)sizeof(TriRec);
-	hdr.magic = kSceneMagic;
-	hdr.blob_bytes = (uint32_t)pt_hip_scene_blob_bytes(n_triangles, n_materials);
-	std::memcpy(base, &hdr, sizeof(hdr));
-	float* tr = (float*)(base + hdr.tri_offset);
+	if (pt_hip_scene_blob_bytes(n_triangles, n_materials) > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "scene_pack: blob larger than 4 GiB");
 	for (uint32_t k = 0; k < n_triangles; k++) {
 		const pt_triangle& t = triangles[k];
 		if (t.vertexIdx0 >= n_vertices || t.vertexIdx1 >= n_vertices || t.vertexIdx2 >= n_vertices)
 			return fail(PT_ERR_INVALID, "scene_pack: triangle " + std::to_string(k) + " has a vertex index out of range");
 		if (t.materialIdx >= n_materials)
 			return fail(PT_ERR_INVALID, "scene_pack: triangle " + std::to_string(k) + " has a material index out of range");
+	}
+	std::memset(base, 0, pt_hip_scene_blob_bytes(n_triangles, n_materials));
+	SceneHeader hdr{};
+	hdr.n_tris = n_triangles; hdr.n_mats = n_materials;
+	hdr.tri_offset = (uint32_t)sizeof(SceneHeader);
+	hdr.mat_offset = hdr.tri_offset + n_triangles * (uint32_t)sizeof(TriRec);
+	hdr.magic = kSceneMagic;
+	hdr.blob_bytes = (uint32_t)pt_hip_scene_blob_bytes(n_triangles, n_materials);
+	hdr.bvh_offset = bvh_offset_of(n_triangles, n_materials);
+	hdr.leaf_offset = hdr.bvh_offset + n_triangles * 64u;
+	{
+		// bounding sphere + (large scenes) the BVH: see pt_bvh.hpp for why the result stays the brute-force one
+		if (n_triangles > g_bvh_min_tris) {
+			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles);
+			if (bvh.nodes.size() > n_triangles) return fail(PT_ERR_LIMIT, "scene_pack: BVH larger than its reservation");
+			hdr.n_nodes = (uint32_t)bvh.nodes.size();
+			std::memcpy(base + hdr.bvh_offset, bvh.nodes.data(), bvh.nodes.size() * sizeof(ptbvh::Node));
+			std::memcpy(base + hdr.leaf_offset, bvh.tris.data(), bvh.tris.size() * sizeof(ptbvh::LeafTri));
+			for (int k = 0; k < 3; k++) hdr.center[k] = bvh.center[k];
+			hdr.radius = bvh.radius;
+			hdr.kappa_root = bvh.kappa_root;
+		}
+	}
+	std::memcpy(base, &hdr, sizeof(hdr));
+	float* tr = (float*)(base + hdr.tri_offset);
+	for (uint32_t k = 0; k < n_triangles; k++) {
+		const pt_triangle& t = triangles[k];
 		const pt_float4 &v0 = vertices[t.vertexIdx0].position, &v1 = vertices[t.vertexIdx1].position, &v2 = vertices[t.vertexIdx2].position;
 		// Functions.cuh:65-66,88 -- the same fp32 subtractions and cross product, done once
 		float e0x = v1.x - v0.x, e0y = v1.y - v0.y, e0z = v1.z - v0.z;
@@ -690,23 +743,18 @@ int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samp
 	HIP_TRY(hipGetLastError());
 	if (frame->pixel_count == 0) return PT_OK;
 	if (hit && (!scene_blob || n_triangles > kShadeLdsMaxTris))
-		return fail(PT_ERR_INVALID, "generate: the fused extend needs a scene of at most 1536 triangles");
+		return fail(PT_ERR_INVALID, "generate: the fused extend needs a scene of at most 1536 triangles (brute force from LDS)");
 	return launch_generate(frame, frame_first, n_samples, rng, sample_matrices, scene_blob, n_triangles,
 	                       (float4*)out.b, (uint2*)hit, s);
 }
 
-int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob, uint32_t n_triangles, pt_queue in,
+int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, pt_queue in,
                   const uint32_t* count, uint32_t capacity, void* hit, void* stream) {
 	if (int rc = check_frame(frame)) return rc;
 	if (!scene_blob || !in.b || !count || !hit || (bounce > 0 && !in.a)) return fail(PT_ERR_INVALID, "extend: null pointer");
 	if (capacity == 0) return PT_OK;
-	FrameDev f = to_dev(*frame);
-	dim3 grid(grid_for(capacity)), block(kBlock);
-	size_t lds = extend_lds_bytes(n_triangles);
-	if (bounce == 0) hipLaunchKernelGGL(k_extend<true>, grid, block, lds, (hipStream_t)stream, f.origin, (const unsigned char*)scene_blob, n_triangles,
-	                                    (const float4*)in.a, (const float4*)in.b, count, capacity, (uint2*)hit);
-	else hipLaunchKernelGGL(k_extend<false>, grid, block, lds, (hipStream_t)stream, f.origin, (const unsigned char*)scene_blob, n_triangles,
-	                        (const float4*)in.a, (const float4*)in.b, count, capacity, (uint2*)hit);
+	launch_extend(to_dev(*frame), bounce, scene_blob, SceneInfo{ n_triangles, n_materials }, (const float4*)in.a, (const float4*)in.b,
+	              count, capacity, (uint2*)hit, (hipStream_t)stream);
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
@@ -783,10 +831,9 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	SceneInfo si{ n_triangles, n_materials };
 	FrameDev f = to_dev(*frame);
 	const bool sequential = frame->rng_mode == PT_RNG_SEQUENTIAL;
-	const size_t ext_lds = extend_lds_bytes(si.n_tris);
 	const uint32_t G = (uint32_t)grid_for(paths_cap);     // queue blocks: fixed for every stage of every pass
 	// scene resident in LDS: extend is fused into generate/shade and there is no separate extend pass
-	const bool fuse = shade_scene_in_lds(si);
+	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si);
 
 	for (uint32_t done = 0; done < n_samples; done += samples_per_pass) {
 		uint32_t ns = std::min(samples_per_pass, n_samples - done);
@@ -796,12 +843,8 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 		                             fuse ? w.hit[0] : nullptr, s)) return rc;
 		for (uint32_t b = 0; b < frame->depth; b++) {
 			int in = b & 1, out = in ^ 1;
-			if (!fuse) {
-				if (b == 0) hipLaunchKernelGGL(k_extend<true>, dim3(G), dim3(kBlock), ext_lds, s, f.origin, (const unsigned char*)scene_blob, si.n_tris,
-				                   (const float4*)w.a[in], (const float4*)w.b[in], (const uint32_t*)(w.counts + (size_t)b * G), (uint32_t)paths_cap, w.hit[in]);
-				else hipLaunchKernelGGL(k_extend<false>, dim3(G), dim3(kBlock), ext_lds, s, f.origin, (const unsigned char*)scene_blob, si.n_tris,
-				                   (const float4*)w.a[in], (const float4*)w.b[in], (const uint32_t*)(w.counts + (size_t)b * G), (uint32_t)paths_cap, w.hit[in]);
-			}
+			if (!fuse)
+				launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
 			pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
 			if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
 			                          fuse ? w.hit[out] : nullptr, w.counts + (size_t)(b + 1) * G,
@@ -830,19 +873,19 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 		host_jump_matrix((uint64_t)frame_first * frame->stride, first.cols);
 		host_jump_matrix(frame->stride, per.cols);
 	}
-	// up to 32 triangles the wave-uniform scene reads go through the scalar cache (s_load) instead
-	// of LDS: +3.5 % measured on the default scene; larger scenes are staged in LDS
-	bool lds = shade_scene_in_lds(si) && si.n_tris > 32;
-	size_t lds_bytes = lds ? shade_lds_bytes(si) : 0;
+	// scene access: up to 32 triangles the wave-uniform reads go through the scalar cache (s_load,
+	// +3.5 % measured on the default scene), up to kBvhMinTris brute force from LDS, above that the BVH
+	int mode = scene_has_bvh(si) ? 2 : (si.n_tris > 32 && shade_scene_in_lds(si)) ? 1 : 0;
+	size_t lds_bytes = mode == 1 ? shade_lds_bytes(si) : 0;
 	// One lane per pixel, every block its own 256 pixels: measured on MI355X (1080p, 64 spp) the
 	// hardware scheduler back-filling 8100 short-lived blocks beats any persistent grid-stride
 	// grid (145 vs 131 Grays/s at 8 blocks/CU) because the kernel holds 77 VGPRs = 6 waves/SIMD and a
 	// persistent grid sized for 8 leaves a one-third-full tail round.
 	dim3 grid((unsigned)(((size_t)frame->pixel_count + kBlock - 1) / kBlock)), block(kBlock);
-#define PT_FUSED(STR, LDS) hipLaunchKernelGGL((k_fused<STR, LDS>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
+#define PT_FUSED(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
-	if (strided) { if (lds) PT_FUSED(true, true); else PT_FUSED(true, false); }
-	else { if (lds) PT_FUSED(false, true); else PT_FUSED(false, false); }
+	if (strided) { if (mode == 2) PT_FUSED(true, 2); else if (mode == 1) PT_FUSED(true, 1); else PT_FUSED(true, 0); }
+	else { if (mode == 2) PT_FUSED(false, 2); else if (mode == 1) PT_FUSED(false, 1); else PT_FUSED(false, 0); }
 #undef PT_FUSED
 	HIP_TRY(hipGetLastError());
 	return PT_OK;

@@ -51,14 +51,14 @@ def test_scene_pack_matches_reference_arithmetic(pt):
     lib = pt.load_library()
     v, t, m = pt.default_scene()
     n = lib.pt_hip_scene_blob_bytes(4, 2)
-    assert n == 32 + 4 * 64 + 2 * 32
+    assert n == 64 + 4 * 64 + 2 * 32            # 64-byte header, 64 B per triangle, 32 B per material (no BVH below 65 triangles)
     blob = (C.c_uint8 * n)()
     rc = lib.pt_hip_scene_pack(C.cast(v, C.c_void_p), 8, C.cast(t, C.c_void_p), 4, C.cast(m, C.c_void_p), 2, C.cast(blob, C.c_void_p), n)
     assert rc == 0, lib.pt_hip_last_error()
     raw = np.frombuffer(blob, dtype=np.uint8)
-    hdr = raw[:32].view(np.uint32)
-    assert hdr[0] == 4 and hdr[1] == 2 and hdr[2] == 32 and hdr[3] == 32 + 256
-    tri = raw[32:32 + 256].view(np.float32).reshape(4, 16)
+    hdr = raw[:64].view(np.uint32)
+    assert hdr[0] == 4 and hdr[1] == 2 and hdr[2] == 64 and hdr[3] == 64 + 256 and hdr[6] == 0     # n_nodes = 0
+    tri = raw[64:64 + 256].view(np.float32).reshape(4, 16)
     f = np.float32
     # triangle 2 = (4,5,6): v0=(-0.2,0.5,0.5) e0=v1-v0 e1=v2-v0, n = cross(e0,e1)  (Functions.cuh:65-66,88)
     v0 = np.array([f(-0.2), f(0.5), f(0.5)]); v1 = np.array([f(0.2), f(0.5), f(0.5)]); v2 = np.array([f(0.2), f(0.5), f(0.9)])
@@ -68,7 +68,7 @@ def test_scene_pack_matches_reference_arithmetic(pt):
     assert np.array_equal(tri[2, 9:12].view(np.uint32), nn.view(np.uint32))
     assert tri[2, 12:13].view(np.uint32)[0] == 1
     assert np.array_equal(tri[0, 9:12], np.array([0, 0, -1], dtype=f))        # the wall's normal
-    mats = raw[32 + 256:].view(np.float32).reshape(2, 8)
+    mats = raw[64 + 256:].view(np.float32).reshape(2, 8)
     assert mats[1, 0:1].view(np.uint32)[0] == pt.PT_MAT_EMISSIVE and list(mats[1, 4:8]) == [10, 10, 10, 10]
 
 
@@ -118,3 +118,64 @@ def test_workspace_size_accounts_for_every_buffer(pt):
     # 2 queues x (3 float4 + pid) + hit + radiance, 256-byte aligned pieces, + counters + matrices
     assert n >= paths * (2 * (48 + 4) + 8 + 16)
     assert n % 256 == 0
+
+
+def test_bvh_blob_is_a_valid_hierarchy(pt):
+    """Scenes above 64 triangles carry a BVH (pathtracer_amd/csrc/pt_bvh.hpp): every triangle is in
+    exactly one leaf, every child box contains its triangles, kappa is the subtree maximum."""
+    import scenes
+    lib = pt.load_library()
+    V, T, M = scenes.synthetic_scene(700)
+    v, t, m = pt.make_scene(V, T, M)
+    n = lib.pt_hip_scene_blob_bytes(len(T), len(M))
+    blob = (C.c_uint8 * n)()
+    assert lib.pt_hip_scene_pack(C.cast(v, C.c_void_p), len(V), C.cast(t, C.c_void_p), len(T), C.cast(m, C.c_void_p), len(M),
+                                 C.cast(blob, C.c_void_p), n) == 0, lib.pt_hip_last_error()
+    raw = np.frombuffer(blob, dtype=np.uint8)
+    hdr_u = raw[:64].view(np.uint32)
+    hdr_f = raw[:64].view(np.float32)
+    n_tris, n_nodes, bvh_off, leaf_off = int(hdr_u[0]), int(hdr_u[6]), int(hdr_u[7]), int(hdr_u[8])
+    assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 64 * n_tris
+    assert hdr_f[12] > 0 and hdr_f[13] > 0                       # radius, kappa_root
+    nodes_f = raw[bvh_off:bvh_off + 64 * n_nodes].view(np.float32).reshape(n_nodes, 16)
+    nodes_i = raw[bvh_off:bvh_off + 64 * n_nodes].view(np.int32).reshape(n_nodes, 16)
+    leaves = raw[leaf_off:leaf_off + 64 * n_tris].view(np.float32).reshape(n_tris, 16)
+    orig = leaves[:, 9].view(np.uint32)
+    assert sorted(orig.tolist()) == list(range(n_tris))          # a permutation
+    P = np.array(V, dtype=np.float32)[:, :3]
+    Tm = np.array(T, dtype=np.int64)
+    seen = np.zeros(n_tris, dtype=int)
+
+    def visit(child, lo, hi, kappa):
+        """returns max kappa of the subtree; checks containment"""
+        if child < 0:
+            code = ~child
+            first, count = code >> 3, (code & 7) + 1
+            kmax = 0.0
+            for k in range(first, first + count):
+                seen[k] += 1
+                tri = Tm[orig[k]]
+                pts = P[tri[:3]]
+                assert (pts >= lo - 1e-7).all() and (pts <= hi + 1e-7).all()
+                e0, e1 = pts[1] - pts[0], pts[2] - pts[0]
+                assert np.array_equal(leaves[k, 0:3], pts[0]) and np.array_equal(leaves[k, 3:6], e0) and np.array_equal(leaves[k, 6:9], e1)
+                kmax = max(kmax, 24 * 2.0**-24 / 1e-6 * np.linalg.norm(e0) * np.linalg.norm(e1))
+            assert kappa >= kmax * (1 - 1e-5)
+            return kmax
+        nf, ni = nodes_f[child], nodes_i[child]
+        k0 = visit(int(ni[12]), nf[0:3], nf[3:6], nf[14])
+        k1 = visit(int(ni[13]), nf[6:9], nf[9:12], nf[15])
+        assert (nf[0:3] >= lo - 1e-7).all() and (nf[3:6] <= hi + 1e-7).all() and (nf[6:9] >= lo - 1e-7).all() and (nf[9:12] <= hi + 1e-7).all()
+        assert kappa >= max(nf[14], nf[15]) * (1 - 1e-6)
+        return max(k0, k1)
+
+    import sys
+    sys.setrecursionlimit(10000)
+    visit(0, np.full(3, -np.inf), np.full(3, np.inf), np.inf)
+    assert (seen == 1).all()
+    # the knob: brute force only
+    assert lib.pt_hip_set_bvh_threshold(0xFFFFFFFF) == 0
+    try:
+        assert lib.pt_hip_scene_blob_bytes(len(T), len(M)) == 64 + 64 * len(T) + 32 * len(M) + (-(64 * len(T) + 32 * len(M)) % 64)
+    finally:
+        lib.pt_hip_set_bvh_threshold(64)

@@ -114,11 +114,16 @@ def test_all_materials_depth16(pt, oracle, name, engine):
     assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
 
 
-@pytest.mark.parametrize("name,engine", ENGINES)
-@pytest.mark.parametrize("n_tris", [12, 300, 1100, 2500])
-def test_synthetic_scenes(pt, oracle, name, engine, n_tris):
-    """BASELINE.json configs[3] at test size; 1100 and 2500 triangles cross the LDS chunk (1024)
-    and the shade-in-LDS (1536) thresholds."""
+@pytest.fixture
+def brute_force_only(pt):
+    """Scenes packed inside this fixture carry no BVH (reference-style loop over all triangles)."""
+    lib = pt.load_library()
+    lib.pt_hip_set_bvh_threshold(0xFFFFFFFF)
+    yield
+    lib.pt_hip_set_bvh_threshold(64)
+
+
+def _synthetic_case(pt, oracle, name, engine, n_tris):
     V, T, M = scenes.synthetic_scene(n_tris)
     w, h, spp = 64, 40, 2
     ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
@@ -129,6 +134,69 @@ def test_synthetic_scenes(pt, oracle, name, engine, n_tris):
         img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
     assert_bit_equal(img, ref, f"{name} {len(T)} triangles")
     assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("n_tris", [12, 64, 66, 300, 1100, 2500, 20000])
+def test_synthetic_scenes(pt, oracle, name, engine, n_tris):
+    """BASELINE.json configs[3] at test size.  Above 64 triangles the extend stage walks a BVH whose
+    answer must be the brute-force one bit for bit (the oracle is brute force)."""
+    _synthetic_case(pt, oracle, name, engine, n_tris)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("n_tris", [300, 1100, 2500])
+def test_synthetic_scenes_brute_force(pt, oracle, name, engine, n_tris, brute_force_only):
+    """The same without the BVH: 1100 and 2500 triangles cross the LDS chunk (1024) and the
+    shade-in-LDS (1536) thresholds of the brute-force path."""
+    _synthetic_case(pt, oracle, name, engine, n_tris)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_bvh_equals_brute_force_on_every_pixel(pt, oracle, name, engine):
+    """10 092 triangles at 960x540: BVH image == brute-force image on all 518 400 pixels (GPU vs GPU),
+    plus 300 pixels against the oracle."""
+    V, T, M = scenes.synthetic_scene(10000)
+    sc = pt.make_scene(V, T, M)
+    w, h, spp = 960, 540, 2
+    lib = pt.load_library()
+    imgs = []
+    for threshold in (64, 0xFFFFFFFF):
+        lib.pt_hip_set_bvh_threshold(threshold)
+        try:
+            with pt.PathTracer(w, h) as tr:
+                tr.set_scene(*sc)
+                tr.set_options(engine=engine)
+                tr.render(spp)
+                imgs.append((tr.readback(), tr.readback_rng(), tr.stats().rays))
+        finally:
+            lib.pt_hip_set_bvh_threshold(64)
+    assert_bit_equal(imgs[0][0], imgs[1][0], f"{name}: BVH vs brute force")
+    assert np.array_equal(imgs[0][1], imgs[1][1]) and imgs[0][2] == imgs[1][2]
+    ids = np.unique(np.random.default_rng(11).integers(0, w * h, 300)).astype(np.uint32)
+    ref, _, _, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M), pixel_ids=ids)
+    assert_bit_equal(imgs[0][0][ids], ref, f"{name}: BVH vs oracle")
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_bvh_with_moved_camera_and_mixed_triangle_sizes(pt, oracle, name, engine):
+    """Big and tiny triangles in one BVH (the all-materials box plus 2000 small ones), camera off-centre."""
+    V, T, M = scenes.all_materials_scene()
+    V2, T2, M2 = scenes.synthetic_scene(2000, seed=77)
+    off, moff = len(V), len(M)
+    V = V + [(x * 0.3, y * 0.3, z * 0.3 + 0.4, w_) for (x, y, z, w_) in V2]
+    T = T + [(a + off, b + off, c + off, m + moff) for (a, b, c, m) in T2]
+    M = M + M2
+    cam = dict(position=(0.2, -0.1, 0.05, 1.0), rotation=(0.02, 0.05, 0.0, 0.998), fov=80.0)
+    w, h, spp = 96, 60, 2
+    ref, _, st_ref, _ = oracle.render(oracle.params(w, h, cam=oracle.make_camera(**cam), depth=12, spp=spp), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h, camera=pt.CameraData(cam["position"], cam["rotation"], cam["fov"])) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine, depth=12)
+        tr.render(spp)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, ref, name)
+    assert st.rays == st_ref.rays
 
 
 @pytest.mark.parametrize("name,engine", ENGINES)

@@ -94,7 +94,7 @@ def test_wavefront_stages_step_by_step(pt, oracle, scene_name, strided, n_sample
         cout = C.c_void_p(counts.ptr + (bounce + 1) * G * 4)
         hit = hits[i_in]
         if not fuse:
-            rc = lib.pt_hip_extend(C.byref(fr), bounce, scene_dev.ptr, len(T), Q[i_in], cin, P, hit.ptr, None)
+            rc = lib.pt_hip_extend(C.byref(fr), bounce, scene_dev.ptr, len(T), len(M), Q[i_in], cin, P, hit.ptr, None)
             assert rc == 0, lib.pt_hip_last_error()
         sync(lib)
         cnt = counts.download(np.uint32)[bounce * G:(bounce + 1) * G]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Measures the other BASELINE.json configs (they are parity-test cases, not bench.py lines):
+C5 all-materials depth 16 and C4 synthetic scenes, both engines, 1080p; spot-checks a few thousand
+pixels of every run against the CPU oracle (bit-exact) and prints one JSON line per run."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import pathtracer_amd as pt           # noqa: E402
+import scenes                          # noqa: E402
+from oracle import pt_oracle_py as po  # noqa: E402
+
+
+def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pass=16):
+    V, T, M = scene
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        if engine == "wavefront":
+            tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT, depth=depth, samples_per_pass=samples_per_pass)
+        else:
+            tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth)
+        tr.render(1)                    # warm-up (also restarts below)
+        tr.set_options(depth=depth)     # restart accumulation
+        t0 = time.perf_counter()
+        tr.render(spp)
+        dt = time.perf_counter() - t0
+        st = tr.stats()
+        img = tr.readback()
+    ok = None
+    if check_pixels:
+        ids = np.unique(np.random.default_rng(3).integers(0, w * h, check_pixels)).astype(np.uint32)
+        ref, _, _, _ = po.render(po.params(w, h, depth=depth, spp=spp), scene=po.make_scene(V, T, M), pixel_ids=ids)
+        ok = bool(np.array_equal(img[ids].view(np.uint32), ref.view(np.uint32)))
+    print(json.dumps({"config": name, "engine": engine, "triangles": len(T), "size": f"{w}x{h}", "spp": spp, "depth": depth,
+                      "rays": int(st.rays), "rays_per_pixel_sample": round(st.rays / (w * h * spp), 3),
+                      "device_ms": round(st.total_render_ms, 3), "wall_ms": round(dt * 1e3, 3),
+                      "Mrays_per_s": round(st.rays / (st.total_render_ms * 1e-3) / 1e6, 1),
+                      "oracle_bit_exact_on_sampled_pixels": ok}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="c5,c4small")
+    ap.add_argument("--spp", type=int, default=64)
+    args = ap.parse_args()
+    which = args.which.split(",")
+    if "c5" in which:
+        for eng in ("fused", "wavefront"):
+            run("C5 all materials depth 16", scenes.all_materials_scene(), 1920, 1080, args.spp, 16, eng)
+    if "c4small" in which:
+        for n in (1000, 10000):
+            sc = scenes.synthetic_scene(n)
+            for eng in ("fused", "wavefront"):
+                run(f"C4 synthetic {n}", sc, 1920, 1080, 4 if n >= 10000 else 16, 10, eng, check_pixels=300)
+    if "c4big" in which:
+        for n in (10000, 30000, 100000):
+            sc = scenes.synthetic_scene(n)
+            run(f"C4 synthetic {n}", sc, 1920, 1080, args.spp, 10, "wavefront", check_pixels=100)
+
+
+if __name__ == "__main__":
+    main()
