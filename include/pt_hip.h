@@ -98,12 +98,12 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* waits for 
 
 /* ---- scene: Vertex/Triangle/Material arrays (Structures.cuh:43-69, upload PathTracer.cu:48-77)
  * packed once on the host into the device blob the kernels stage in LDS: per triangle
- * {v0, e0=v1-v0, e1=v2-v0, n=cross(e0,e1), materialIdx}, per material {type, color}; above 64
+ * {v0, e0=v1-v0, e1=v2-v0, n=cross(e0,e1), materialIdx}, per material {type, color}; above 512
  * triangles also a BVH (64-byte nodes + 64-byte leaf records).
  * Validates vertex and material indices.  The blob is position independent: copy it to the
  * device with pt_hip_memcpy_h2d.  Entry points that take `scene_blob` also take the triangle and
  * material counts it was packed with. */
-/* Process-wide tuning knob: scenes with more than `min_triangles` triangles get a BVH (default 64;
+/* Process-wide tuning knob: scenes with more than `min_triangles` triangles get a BVH (default 512, the measured crossover;
  * 0xFFFFFFFF = always brute force like the reference).  Call before packing/uploading a scene; blobs
  * packed under another threshold must not be used afterwards.  Results do not depend on it. */
 int pt_hip_set_bvh_threshold(uint32_t min_triangles);
@@ -152,7 +152,7 @@ int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samp
 /* a5+a6: TraverseScene + RayIntersectsTriangle (kernels.cu:57-69, Functions.cuh:56-89).
  * For every queued entry (counts[b] per block): closest accepted hit (t > EPSILON && t < best_t,
  * first index wins ties), written as hit[slot] = {t or unchanged best_t, triangle index or
- * 0xFFFFFFFF}.  Scenes of up to 64 triangles loop over all of them (from LDS) like the reference;
+ * 0xFFFFFFFF}.  Scenes of up to 512 triangles loop over all of them (from LDS) like the reference;
  * larger ones carry a BVH in their blob and are traversed with it -- a culling structure only,
  * the accepted hit is the brute-force one bit for bit (pathtracer_amd/csrc/pt_bvh.hpp). */
 int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,

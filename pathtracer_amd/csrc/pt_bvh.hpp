@@ -10,7 +10,10 @@
 //     |du| * |e0|  <~  c * eps * |d| * |e0||e1| * (|s| + |e0|) / det   <=  c * eps * |e0||e1| * S / EPSILON
 // (|d| <= 1 for every ray this tracer makes, S bounds |origin - vertex| + edge length), likewise for v
 // and for t.  So the true ray/plane intersection of an accepted hit lies within
-//     delta_i = kappa_i * S,   kappa_i = 24 * eps * |e0||e1| / EPSILON        (c = 24: 3x head-room)
+//     delta_i = kappa_i * S,   kappa_i = 16 * eps * |e0||e1| / EPSILON
+// (a term-by-term bound gives 7 eps (|s| + |e0|) |d||e0||e1| / det_true with det_true >= 0.64 EPSILON for
+// |e0||e1| <= 1, i.e. c = 11; 16 leaves head-room, and triangles with |e0||e1| >> 1 get boxes larger than
+// the scene, which is what their unbounded error needs).
 // of triangle i.  Each child box stores the max kappa of its subtree; the traversal inflates the box
 // by kappa * S + a relative slack for its own arithmetic, and widens the ray interval by the root's
 // delta.  Small triangles (the 10^4..10^5-triangle scenes this is for) get small inflations
@@ -30,7 +33,7 @@ namespace ptbvh {
 
 constexpr uint32_t kLeafSize = 4;
 constexpr float kEps32 = 5.9604645e-8f;            // 2^-24
-constexpr float kKappaScale = 24.0f * kEps32 / 0.000001f;
+constexpr float kKappaScale = 16.0f * kEps32 / 0.000001f;
 
 // 64 bytes: the two children's boxes live in the parent.
 struct Node {
@@ -50,6 +53,7 @@ struct Built {
 	float center[3] = { 0, 0, 0 };
 	float radius = 0.0f;
 	float kappa_root = 0.0f;
+	float max_edge = 0.0f;
 };
 
 struct Prim { float lo[3], hi[3], c[3]; float kappa; uint32_t idx; };
@@ -108,6 +112,9 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris) {
 		float l0 = std::sqrt(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2]);
 		float l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
 		pr.kappa = kKappaScale * l0 * l1;
+		float e2[3] = { e1[0] - e0[0], e1[1] - e0[1], e1[2] - e0[2] };
+		float l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+		out.max_edge = std::max(out.max_edge, std::max(l0, std::max(l1, l2)));
 		pr.idx = i;
 	}
 	float r2 = 0.0f;

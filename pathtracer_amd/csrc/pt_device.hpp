@@ -104,12 +104,13 @@ struct SceneHeader {                                   // 64 bytes
 	uint32_t leaf_offset;
 	float    center[3], radius;                        // bounding sphere of the vertices
 	float    kappa_root;                               // see pt_bvh.hpp
-	uint32_t _pad[2];
+	float    max_edge;                                 // longest triangle edge
+	uint32_t _pad[1];
 };
 static_assert(sizeof(SceneHeader) == 64, "SceneHeader is 64 bytes");
 
 // Scenes above this many triangles carry a BVH and are traversed with it (pt_bvh.hpp).
-constexpr uint32_t kBvhMinTris = 64;
+constexpr uint32_t kBvhMinTris = 512;    // measured crossover on MI355X: brute force wins at 432 triangles, the BVH 2-3x at 972
 constexpr int kBvhStackDepth = 24;                     // per-lane stack of deferred nodes, in LDS
 
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
@@ -151,9 +152,10 @@ __device__ __forceinline__ void intersect_range(const float4* __restrict__ tris,
 struct BvhView {
 	const float4* nodes;     // 4 float4 per node
 	const float4* leaves;    // 4 float4 per triangle, BVH order
-	float s_bound;           // bound on |ray origin - vertex| + edge length for this launch
+	float s_bound;           // bound on |ray origin - vertex| + edge length for any ray of this launch
 	float slack;             // absolute slack of the box arithmetic
-	float delta_root;        // kappa_root * s_bound: how far outside its triangle an accepted hit can be
+	float kappa_root;        // largest kappa in the scene
+	float max_edge;          // longest triangle edge
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -163,11 +165,14 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	v.nodes = reinterpret_cast<const float4*>(scene + off);
 	v.leaves = reinterpret_cast<const float4*>(scene + off + (size_t)n_tris * 64u);
 	float dx = origin.x - hdr->center[0], dy = origin.y - hdr->center[1], dz = origin.z - hdr->center[2];
-	// every ray starts at the camera or on a triangle: |origin - vertex| <= |camera - centre| + 2 radius; edges <= 2 radius
-	v.s_bound = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) + 4.0f * hdr->radius;
+	// a ray starts at the camera or (within an epsilon) on a triangle, a vertex lies in the bounding sphere:
+	// |origin - vertex| <= max(|camera - centre| + radius, 2 radius); plus the edge term of the error bound
+	float cam = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+	v.s_bound = 1.001f * (fmaxf(cam + hdr->radius, 2.0f * hdr->radius) + hdr->max_edge) + 1e-5f;
 	float cmag = fabsf(hdr->center[0]) + fabsf(hdr->center[1]) + fabsf(hdr->center[2]) + hdr->radius;
-	v.slack = 2e-6f * (cmag + v.s_bound);
-	v.delta_root = hdr->kappa_root * v.s_bound + v.slack;
+	v.slack = 2e-6f * (cmag + v.s_bound + cam);
+	v.kappa_root = hdr->kappa_root;
+	v.max_edge = hdr->max_edge;
 	return v;
 }
 
@@ -207,7 +212,12 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 	         fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z };
 	Vec3 inv{ 1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z };
 	float dlen = __builtin_sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
-	float dt = 1.01f * bv.delta_root / dlen;            // the root delta in ray-parameter units
+	// S for THIS ray: an accepted hit has computed t < best_t, so its vertex is no farther from the origin
+	// than best_t*|d| + edge (+ the error delta itself, bounded with the launch-wide S); never more than s_bound
+	float delta_max = bv.kappa_root * bv.s_bound + bv.slack;
+	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
+	float delta_root = bv.kappa_root * s_ray + bv.slack;   // how far outside its triangle an accepted hit can be
+	float dt = 1.01f * delta_root / dlen;                  // ... in ray-parameter units
 	float tlo = -dt;
 	uint32_t cur = 0;
 	int sp = 0;
@@ -217,8 +227,8 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 		int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
 		float thi = best_t + dt + 1e-6f * best_t;
 		float tn0, tn1;
-		bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * bv.s_bound + bv.slack, o, inv, tlo, thi, tn0);
-		bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * bv.s_bound + bv.slack, o, inv, tlo, thi, tn1);
+		bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * s_ray + bv.slack, o, inv, tlo, thi, tn0);
+		bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * s_ray + bv.slack, o, inv, tlo, thi, tn1);
 		if (h0 && c0 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c0, o, d, best_t, hit_tri); h0 = false; }
 		if (h1 && c1 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c1, o, d, best_t, hit_tri); h1 = false; }
 		if (h0 && h1) {

@@ -687,6 +687,7 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			for (int k = 0; k < 3; k++) hdr.center[k] = bvh.center[k];
 			hdr.radius = bvh.radius;
 			hdr.kappa_root = bvh.kappa_root;
+			hdr.max_edge = bvh.max_edge;
 		}
 	}
 	std::memcpy(base, &hdr, sizeof(hdr));

@@ -51,7 +51,7 @@ def test_scene_pack_matches_reference_arithmetic(pt):
     lib = pt.load_library()
     v, t, m = pt.default_scene()
     n = lib.pt_hip_scene_blob_bytes(4, 2)
-    assert n == 64 + 4 * 64 + 2 * 32            # 64-byte header, 64 B per triangle, 32 B per material (no BVH below 65 triangles)
+    assert n == 64 + 4 * 64 + 2 * 32            # 64-byte header, 64 B per triangle, 32 B per material (no BVH up to 512 triangles)
     blob = (C.c_uint8 * n)()
     rc = lib.pt_hip_scene_pack(C.cast(v, C.c_void_p), 8, C.cast(t, C.c_void_p), 4, C.cast(m, C.c_void_p), 2, C.cast(blob, C.c_void_p), n)
     assert rc == 0, lib.pt_hip_last_error()
@@ -121,7 +121,7 @@ def test_workspace_size_accounts_for_every_buffer(pt):
 
 
 def test_bvh_blob_is_a_valid_hierarchy(pt):
-    """Scenes above 64 triangles carry a BVH (pathtracer_amd/csrc/pt_bvh.hpp): every triangle is in
+    """Scenes above 512 triangles carry a BVH (pathtracer_amd/csrc/pt_bvh.hpp): every triangle is in
     exactly one leaf, every child box contains its triangles, kappa is the subtree maximum."""
     import scenes
     lib = pt.load_library()
@@ -159,7 +159,7 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
                 assert (pts >= lo - 1e-7).all() and (pts <= hi + 1e-7).all()
                 e0, e1 = pts[1] - pts[0], pts[2] - pts[0]
                 assert np.array_equal(leaves[k, 0:3], pts[0]) and np.array_equal(leaves[k, 3:6], e0) and np.array_equal(leaves[k, 6:9], e1)
-                kmax = max(kmax, 24 * 2.0**-24 / 1e-6 * np.linalg.norm(e0) * np.linalg.norm(e1))
+                kmax = max(kmax, 16 * 2.0**-24 / 1e-6 * np.linalg.norm(e0) * np.linalg.norm(e1))
             assert kappa >= kmax * (1 - 1e-5)
             return kmax
         nf, ni = nodes_f[child], nodes_i[child]
@@ -178,4 +178,4 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     try:
         assert lib.pt_hip_scene_blob_bytes(len(T), len(M)) == 64 + 64 * len(T) + 32 * len(M) + (-(64 * len(T) + 32 * len(M)) % 64)
     finally:
-        lib.pt_hip_set_bvh_threshold(64)
+        lib.pt_hip_set_bvh_threshold(512)
