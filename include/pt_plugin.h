@@ -83,6 +83,16 @@ int pt_set_scene(pt_handle* h, const pt_vertex* vertices, uint32_t n_vertices,
                  const pt_triangle* triangles, uint32_t n_triangles,
                  const pt_material* materials, uint32_t n_materials);
 
+/* Scene files (pathtracer_amd/csrc/pt_scene_io.hpp: OBJ subset {v, f, usemtl} + 'm' material and 't' raw
+ * triangle records).  pt_scene_file_read parses on the host into malloc'ed arrays of the reference PODs
+ * (release each with pt_scene_file_free); pt_load_scene = read + pt_set_scene. */
+int pt_scene_file_read(const char* path, pt_vertex** vertices, uint32_t* n_vertices,
+                       pt_triangle** triangles, uint32_t* n_triangles, pt_material** materials, uint32_t* n_materials);
+void pt_scene_file_free(void* array);
+int pt_scene_file_write(const char* path, const pt_vertex* vertices, uint32_t n_vertices,
+                        const pt_triangle* triangles, uint32_t n_triangles, const pt_material* materials, uint32_t n_materials);
+int pt_load_scene(pt_handle* h, const char* path);
+
 /* spp x (BeginDrawing; FinalizeDrawing) as one device submission; honours a pending restart. */
 int pt_render(pt_handle* h, uint32_t spp);
 

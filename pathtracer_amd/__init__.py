@@ -100,6 +100,10 @@ SYMBOLS = {
     "pt_get_options": (C.c_int, [_VP, C.POINTER(Options)]),
     "pt_set_options": (C.c_int, [_VP, C.POINTER(Options)]),
     "pt_set_scene": (C.c_int, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
+    "pt_scene_file_read": (C.c_int, [C.c_char_p, C.POINTER(_VP), _U32P, C.POINTER(_VP), _U32P, C.POINTER(_VP), _U32P]),
+    "pt_scene_file_free": (None, [_VP]),
+    "pt_scene_file_write": (C.c_int, [C.c_char_p, _VP, _U32, _VP, _U32, _VP, _U32]),
+    "pt_load_scene": (C.c_int, [_VP, C.c_char_p]),
     "pt_render": (C.c_int, [_VP, _U32]),
     "pt_readback": (C.c_int, [_VP, _VP, _SZ]),
     "pt_readback_rng": (C.c_int, [_VP, _VP, _SZ]),
@@ -190,6 +194,29 @@ def make_scene(vertices, triangles, materials):
     return v, t, m
 
 
+def read_scene_file(path: str):
+    """Parse a scene file on the host (no GPU): returns (vertices, triangles, materials) ctypes arrays."""
+    lib = load_library()
+    pv, pt_, pm = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nv, nt, nm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _check(lib.pt_scene_file_read(os.fsencode(path), C.byref(pv), C.byref(nv), C.byref(pt_), C.byref(nt), C.byref(pm), C.byref(nm)),
+           lib, "pt_scene_file_read")
+    try:
+        v = (Vertex * nv.value).from_buffer_copy(C.string_at(pv.value, nv.value * 16)) if nv.value else (Vertex * 0)()
+        t = (Triangle * nt.value).from_buffer_copy(C.string_at(pt_.value, nt.value * 16)) if nt.value else (Triangle * 0)()
+        m = (Material * nm.value).from_buffer_copy(C.string_at(pm.value, nm.value * 48)) if nm.value else (Material * 0)()
+    finally:
+        for p in (pv, pt_, pm):
+            lib.pt_scene_file_free(p)
+    return v, t, m
+
+
+def write_scene_file(path: str, vertices, triangles, materials) -> None:
+    lib = load_library()
+    _check(lib.pt_scene_file_write(os.fsencode(path), C.cast(vertices, C.c_void_p), len(vertices), C.cast(triangles, C.c_void_p),
+                                   len(triangles), C.cast(materials, C.c_void_p), len(materials)), lib, "pt_scene_file_write")
+
+
 class PathTracer:
     """The plugin behind the reference's IPathTracer surface, plus the headless extras.
 
@@ -260,6 +287,9 @@ class PathTracer:
     def set_scene(self, vertices, triangles, materials) -> None:
         _check(self._lib.pt_set_scene(self._h, C.cast(vertices, C.c_void_p), len(vertices), C.cast(triangles, C.c_void_p),
                                       len(triangles), C.cast(materials, C.c_void_p), len(materials)), self._lib, "pt_set_scene")
+
+    def load_scene(self, path: str) -> None:
+        _check(self._lib.pt_load_scene(self._h, os.fsencode(path)), self._lib, "pt_load_scene")
 
     def render(self, spp: int) -> None:
         _check(self._lib.pt_render(self._h, int(spp)), self._lib, "pt_render")

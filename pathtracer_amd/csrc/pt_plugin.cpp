@@ -22,6 +22,7 @@
 #include "pt_hip.h"
 #include "pt_plugin.h"
 #include "pt_camera.hpp"
+#include "pt_scene_io.hpp"
 
 namespace {
 
@@ -392,6 +393,34 @@ int pt_set_options(pt_handle* h, const pt_options* in) {
 int pt_set_scene(pt_handle* h, const pt_vertex* v, uint32_t nv, const pt_triangle* t, uint32_t nt, const pt_material* m, uint32_t nm) {
 	PT_HANDLE(h);
 	return tracer->SetScene(v, nv, t, nt, m, nm);
+}
+int pt_scene_file_read(const char* path, pt_vertex** v, uint32_t* nv, pt_triangle** t, uint32_t* nt, pt_material** m, uint32_t* nm) {
+	if (!path || !v || !nv || !t || !nt || !m || !nm) return plugin_fail(PT_ERR_INVALID, "scene_file_read: null pointer");
+	ptio::Scene sc;
+	std::string err = ptio::read(path, sc);
+	if (!err.empty()) return plugin_fail(PT_ERR_INVALID, err);
+	auto dup = [](const void* src, size_t bytes) { void* p = std::malloc(bytes ? bytes : 1); if (p && bytes) std::memcpy(p, src, bytes); return p; };
+	*v = (pt_vertex*)dup(sc.vertices.data(), sc.vertices.size() * sizeof(pt_vertex));
+	*t = (pt_triangle*)dup(sc.triangles.data(), sc.triangles.size() * sizeof(pt_triangle));
+	*m = (pt_material*)dup(sc.materials.data(), sc.materials.size() * sizeof(pt_material));
+	if (!*v || !*t || !*m) { std::free(*v); std::free(*t); std::free(*m); return plugin_fail(PT_ERR_NOMEM, "scene_file_read: out of memory"); }
+	*nv = (uint32_t)sc.vertices.size(); *nt = (uint32_t)sc.triangles.size(); *nm = (uint32_t)sc.materials.size();
+	return PT_OK;
+}
+void pt_scene_file_free(void* array) { std::free(array); }
+int pt_scene_file_write(const char* path, const pt_vertex* v, uint32_t nv, const pt_triangle* t, uint32_t nt, const pt_material* m, uint32_t nm) {
+	if (!path || (!v && nv) || (!t && nt) || (!m && nm)) return plugin_fail(PT_ERR_INVALID, "scene_file_write: null pointer");
+	std::string err = ptio::write(path, v, nv, t, nt, m, nm);
+	return err.empty() ? PT_OK : plugin_fail(PT_ERR_INVALID, err);
+}
+int pt_load_scene(pt_handle* h, const char* path) {
+	PT_HANDLE(h);
+	if (!path) return plugin_fail(PT_ERR_INVALID, "load_scene: null path");
+	ptio::Scene sc;
+	std::string err = ptio::read(path, sc);
+	if (!err.empty()) return plugin_fail(PT_ERR_INVALID, err);
+	return tracer->SetScene(sc.vertices.data(), (uint32_t)sc.vertices.size(), sc.triangles.data(), (uint32_t)sc.triangles.size(),
+	                        sc.materials.data(), (uint32_t)sc.materials.size());
 }
 int pt_render(pt_handle* h, uint32_t spp) { PT_HANDLE(h); return tracer->Render(spp); }
 int pt_readback(pt_handle* h, float* rgba, size_t n_floats) { PT_HANDLE(h); return tracer->Readback(rgba, n_floats); }
