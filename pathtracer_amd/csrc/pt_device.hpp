@@ -81,8 +81,47 @@ __device__ __forceinline__ float rng_uniform(uint32_t& s) {
 	return (float)s * 2.3283064365386963e-10f;
 }
 
-// helper_math.h:62-65 host form of rsqrtf; HIP's default fp32 divide and sqrt are correctly rounded.
-__device__ __forceinline__ float rsqrt_ref(float x) { return 1.0f / __builtin_sqrtf(x); }
+// ---- exact fp32 reciprocal and square root in fewer VALU cycles ----
+// The kernels are VALU-bound and divide ~13 times per pixel-sample.  hipcc expands an IEEE fp32 division into 11
+// instructions (2 v_div_scale, v_rcp, 5 fma/mul, v_div_fmas, v_div_fixup: 37 issue cycles, tools/valu_microbench.hip)
+// and an IEEE sqrt into v_sqrt + range scaling + a +-1 ulp residual fix-up.  For operands that are neither tiny nor
+// huge the scaling and the special-case fix-ups are dead weight:
+//   rcp_newton(x)  = v_rcp_f32 (1 ulp) + ONE fused Newton step         == 1.0f / x    for 2^-126 <= |x| < 2^126
+//   sqrt_fixup(x)  = v_sqrt_f32 (1 ulp) + the +-1 ulp residual fix-up  == sqrtf(x)    for 2^-100 <= x < 2^128
+//                    (below 2^-104 the residuals underflow and 1 in 4 results is off by an ulp)
+// "==" is bit for bit and is not an estimate: tests/proofs/exact_rcp_sqrt.hip compares both with the compiler's
+// IEEE expansions over ALL 2^32 bit patterns on the GPU (tests/test_gpu_proofs.py).  rcp_ieee / sqrt_ieee are the
+// guarded forms for operands of unknown range (plain division / sqrtf outside it); the unguarded forms are used only
+// where the range is known, and each such site says why.
+constexpr float kRcpLo = 1.1754944e-38f;             // 2^-126
+constexpr float kRcpHi = 4.2535296e37f;              // 2^125 (inclusive bound; the proof covers up to < 2^126)
+constexpr float kSqrtLo = 7.888609e-31f;             // 2^-100
+__device__ __forceinline__ float rcp_newton(float x) {
+	float r = __builtin_amdgcn_rcpf(x);
+	float e = __builtin_fmaf(-x, r, 1.0f);
+	return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float rcp_ieee(float x) {
+	float a = __builtin_fabsf(x);
+	if (__builtin_expect(a >= kRcpLo && a <= kRcpHi, 1)) return rcp_newton(x);
+	return 1.0f / x;
+}
+__device__ __forceinline__ float sqrt_fixup(float x) {
+	float s = __builtin_amdgcn_sqrtf(x);
+	float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+	float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+	s = r_dn <= 0.0f ? s_dn : s;
+	return r_up > 0.0f ? s_up : s;
+}
+__device__ __forceinline__ float sqrt_ieee(float x) {
+	if (__builtin_expect(x >= kSqrtLo && x <= 3.0e38f, 1)) return sqrt_fixup(x);
+	return __builtin_sqrtf(x);
+}
+
+// helper_math.h:62-65 host form of rsqrtf = 1.0f / sqrtf(x): two correctly rounded operations.
+__device__ __forceinline__ float rsqrt_ref(float x) { return rcp_ieee(sqrt_ieee(x)); }
+// the same for 2^-100 <= x < 2^128: sqrt is then in [2^-50, 2^64)
+__device__ __forceinline__ float rsqrt_ref_bounded(float x) { return rcp_newton(sqrt_fixup(x)); }
 
 struct Vec3 { float x, y, z; };
 
@@ -105,8 +144,9 @@ struct SceneHeader {                                   // 64 bytes
 	float    center[3], radius;                        // bounding sphere of the vertices
 	float    kappa_root;                               // see pt_bvh.hpp
 	float    max_edge;                                 // longest triangle edge
-	uint32_t _pad[1];
+	uint32_t flags;                                    // kSceneDetBounded
 };
+constexpr uint32_t kSceneDetBounded = 1u;              // max |e0|*|e1| < 2^100: see ray_triangle
 static_assert(sizeof(SceneHeader) == 64, "SceneHeader is 64 bytes");
 
 // Scenes above this many triangles carry a BVH and are traversed with it (pt_bvh.hpp).
@@ -120,11 +160,14 @@ constexpr uint32_t kSceneMagic = 0x50544853u;  // "PTHS"
 
 // Moeller-Trumbore with culling, Functions.cuh:56-89.  Returns true and t unless the reference
 // returns NO_INTERSECTION.  e0/e1 are the precomputed v1-v0 / v2-v0 (same fp32 subtraction).
-__device__ __forceinline__ bool ray_triangle(Vec3 o, Vec3 d, Vec3 v0, Vec3 e0, Vec3 e1, float& t) {
+// det_bounded (wave-uniform, SceneHeader::flags): every |e0|*|e1| of the scene is below 2^100, so for |d| < 2^20
+// (the path's own directions have |d| <= 1) EPS <= det < 2^121 here and rcp_newton IS the division.
+__device__ __forceinline__ bool ray_triangle(Vec3 o, Vec3 d, Vec3 v0, Vec3 e0, Vec3 e1, bool det_bounded, float& t) {
 	Vec3 h = cross3(d, e1);
 	float det = dot3(e0, h);
 	if (det < kEpsilon) return false;            // :72
-	float f = 1.0f / det;                        // :77
+	float f;                                     // :77  1.0f / det
+	if (det_bounded) f = rcp_newton(det); else f = 1.0f / det;
 	Vec3 s = Vec3{ o.x - v0.x, o.y - v0.y, o.z - v0.z };
 	float u = f * dot3(s, h);                    // :80
 	if (u < 0.0f || u > 1.0f) return false;
@@ -137,12 +180,12 @@ __device__ __forceinline__ bool ray_triangle(Vec3 o, Vec3 d, Vec3 v0, Vec3 e0, V
 
 // TraverseScene's loop body for a range of packed triangles (kernels.cu:62-68): closest
 // accepted hit, strict '<' so the first index wins ties; best_t is carried in and out.
-__device__ __forceinline__ void intersect_range(const float4* __restrict__ tris, uint32_t first, uint32_t n,
+__device__ __forceinline__ void intersect_range(const float4* __restrict__ tris, uint32_t first, uint32_t n, bool det_bounded,
                                                 Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri) {
 	for (uint32_t k = 0; k < n; k++) {
 		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
 		float t;
-		if (ray_triangle(o, d, Vec3{ r0.x, r0.y, r0.z }, Vec3{ r0.w, r1.x, r1.y }, Vec3{ r1.z, r1.w, r2.x }, t)) {
+		if (ray_triangle(o, d, Vec3{ r0.x, r0.y, r0.z }, Vec3{ r0.w, r1.x, r1.y }, Vec3{ r1.z, r1.w, r2.x }, det_bounded, t)) {
 			if (t > kEpsilon && t < best_t) { best_t = t; hit_tri = first + k; }   // :64
 		}
 	}
@@ -156,6 +199,7 @@ struct BvhView {
 	float slack;             // absolute slack of the box arithmetic
 	float kappa_root;        // largest kappa in the scene
 	float max_edge;          // longest triangle edge
+	bool det_bounded;        // SceneHeader::flags bit 0
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -173,6 +217,7 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	v.slack = 2e-6f * (cmag + v.s_bound + cam);
 	v.kappa_root = hdr->kappa_root;
 	v.max_edge = hdr->max_edge;
+	v.det_bounded = (hdr->flags & kSceneDetBounded) != 0;
 	return v;
 }
 
@@ -189,14 +234,14 @@ __device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, 
 	return t0 <= t1 + 1e-5f * fabsf(t1);
 }
 
-__device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint32_t code, Vec3 o, Vec3 d,
+__device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint32_t code, bool det_bounded, Vec3 o, Vec3 d,
                                          float& best_t, uint32_t& hit_tri) {
 	uint32_t first = code >> 3, count = (code & 7u) + 1u;
 	for (uint32_t k = 0; k < count; k++) {
 		const float4* rec = leaves + (size_t)(first + k) * 4;
 		float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
 		float t;
-		if (ray_triangle(o, d, Vec3{ r0.x, r0.y, r0.z }, Vec3{ r0.w, r1.x, r1.y }, Vec3{ r1.z, r1.w, r2.x }, t)) {
+		if (ray_triangle(o, d, Vec3{ r0.x, r0.y, r0.z }, Vec3{ r0.w, r1.x, r1.y }, Vec3{ r1.z, r1.w, r2.x }, det_bounded, t)) {
 			uint32_t idx = __float_as_uint(r2.y);
 			// kernels.cu:64 over ALL triangles in index order == min over (t, index): ties go to the lower index
 			if (t > kEpsilon && (t < best_t || (t == best_t && hit_tri != kNoHit && idx < hit_tri))) { best_t = t; hit_tri = idx; }
@@ -229,8 +274,8 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 		float tn0, tn1;
 		bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * s_ray + bv.slack, o, inv, tlo, thi, tn0);
 		bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * s_ray + bv.slack, o, inv, tlo, thi, tn1);
-		if (h0 && c0 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c0, o, d, best_t, hit_tri); h0 = false; }
-		if (h1 && c1 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c1, o, d, best_t, hit_tri); h1 = false; }
+		if (h0 && c0 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c0, bv.det_bounded, o, d, best_t, hit_tri); h0 = false; }
+		if (h1 && c1 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c1, bv.det_bounded, o, d, best_t, hit_tri); h1 = false; }
 		if (h0 && h1) {
 			bool first0 = tn0 <= tn1;
 			if (sp < kBvhStackDepth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }
@@ -256,10 +301,13 @@ __device__ __forceinline__ void diffuse_reflection(Vec3 n, const uint32_t* __res
 	uint32_t x1 = xs_step(x0);                  // draw 32
 	uint32_t x2 = xs_step(x1);                  // draw 33
 	rng = x2;
-	float ax = (float)x0 * 2.3283064365386963e-10f * 2.0f - 1.0f;   // :100-101
-	float ay = (float)x1 * 2.3283064365386963e-10f * 2.0f - 1.0f;
-	float az = (float)x2 * 2.3283064365386963e-10f * 2.0f - 1.0f;
-	float inv = rsqrt_ref(ax * ax + ay * ay + az * az + 1.0f);      // :107, w = -1 (:101)
+	// :100-101  u * 2.0f - 1.0f with u = (float)x * 2^-32: both scalings are exact (powers of two, no underflow
+	// since x >= 1), so ONE fma by 2^-31 returns the same bits as the reference's three roundings
+	float ax = __builtin_fmaf((float)x0, 4.656612873077393e-10f, -1.0f);
+	float ay = __builtin_fmaf((float)x1, 4.656612873077393e-10f, -1.0f);
+	float az = __builtin_fmaf((float)x2, 4.656612873077393e-10f, -1.0f);
+	// :107, w = -1 (:101): the squared length is in [1, 4], far inside the proven range of the short forms
+	float inv = rsqrt_ref_bounded(ax * ax + ay * ay + az * az + 1.0f);
 	ax *= inv; ay *= inv; az *= inv;
 	float aw = -1.0f * inv;
 	// :108  dot(result, normal) > 0 ; the dropped w term is (aw * +0) = -0, an exact identity
@@ -304,7 +352,7 @@ __device__ __forceinline__ Vec3 primary_direction(const FrameDev& f, uint32_t px
 
 // DrawToTexture's running mean, kernels.cu:17-18.
 __device__ __forceinline__ float4 running_mean(float4 color, float4 prev, uint32_t frame_number) {
-	float rcp = 1.0f / (float)(frame_number + 1u);
+	float rcp = rcp_newton((float)(frame_number + 1u));        // 1.0f / (n+1); n+1 in [1, 2^32]: proven range
 	float n = (float)frame_number;
 	return float4{ color.x * rcp + prev.x * n * rcp, color.y * rcp + prev.y * n * rcp,
 	               color.z * rcp + prev.z * n * rcp, color.w * rcp + prev.w * n * rcp };

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -105,6 +106,11 @@ void host_jump_matrix(uint64_t k, uint32_t cols[32]) {
 }
 
 struct JumpMat { uint32_t cols[32]; };
+
+// SceneHeader::flags bit 0 (wave-uniform scalar load): pt_device.hpp, ray_triangle
+__device__ __forceinline__ bool scene_det_bounded(const unsigned char* scene) {
+	return scene && (reinterpret_cast<const SceneHeader*>(scene)->flags & kSceneDetBounded) != 0;
+}
 struct SceneInfo { uint32_t n_tris, n_mats; };
 
 // ------------------------------------------------------------------------------- kernels
@@ -140,6 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev f, const uint32_t*
                                                      const unsigned char* __restrict__ scene, uint32_t n_tris,
                                                      float4* __restrict__ qb, uint2* __restrict__ hit) {
 	extern __shared__ float4 s_tris[];
+	const bool det_bounded = scene_det_bounded(scene);
 	if (EXTEND) {
 		const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 		for (uint32_t k = threadIdx.x; k < n_tris * 4; k += kBlock) s_tris[k] = g_tris[k];
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev f, const uint32_t*
 		if (EXTEND) {
 			float best = FLT_MAX;
 			uint32_t tri = kNoHit;
-			intersect_range(s_tris, 0, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, d, best, tri);
+			intersect_range(s_tris, 0, n_tris, det_bounded, Vec3{ f.origin.x, f.origin.y, f.origin.z }, d, best, tri);
 			hit[p] = uint2{ __float_as_uint(best), tri };
 		}
 	}
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const uint32_t G = gridDim.x;
 	const uint32_t count = count_ptr[blockIdx.x];
+	const bool det_bounded = scene_det_bounded(scene);
 	__shared__ uint32_t s_stack[BVH ? kBvhStackDepth * kBlock : 1];
 	BvhView bv{};
 	if (BVH) bv = make_bvh_view(scene, n_tris, n_mats, camera);
@@ -218,14 +226,14 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 		if (BVH) {
 			if (active) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
 		} else if (single) {
-			if (active) intersect_range(s_tris, 0, n_tris, o, d, best, tri);
+			if (active) intersect_range(s_tris, 0, n_tris, det_bounded, o, d, best, tri);
 		} else {
 			for (uint32_t c0 = 0; c0 < n_tris; c0 += kLdsTriChunk) {
 				uint32_t cn = min(kLdsTriChunk, n_tris - c0);
 				__syncthreads();
 				for (uint32_t k = threadIdx.x; k < cn * 4; k += kBlock) s_tris[k] = g_tris[(size_t)c0 * 4 + k];
 				__syncthreads();
-				if (active) intersect_range(s_tris, c0, cn, o, d, best, tri);
+				if (active) intersect_range(s_tris, c0, cn, det_bounded, o, d, best, tri);
 			}
 		}
 		if (active) hit[q] = uint2{ __float_as_uint(best), tri };
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
 	stage_jump31(s_jump);
+	const bool det_bounded = scene_det_bounded(scene);
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const float4* g_mats = g_tris + (size_t)n_tris * 4;
 	const float4* tris = g_tris;
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 				rng = __float_as_uint(b.w);
 				shade_diffuse(n, color, t, s_jump, o, d, step, rng);
 				cont = true;
-				if (EXTEND && !last_bounce) intersect_range(tris, 0, n_tris, o, d, t, next_tri);
+				if (EXTEND && !last_bounce) intersect_range(tris, 0, n_tris, det_bounded, o, d, t, next_tri);
 			} else {
 				if (type == PT_MAT_EMISSIVE) {
 					if (!FIRST) step = qc[q];
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_stack[BVH ? kBvhStackDepth * kBlock : 1];
 	stage_jump31(s_jump);
+	const bool det_bounded = scene_det_bounded(scene);
 	BvhView bv{};
 	if (BVH) bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
 	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 				n_rays++;
 				uint32_t tri = kNoHit;
 				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
-				else intersect_range(tris, 0, n_tris, o, d, best, tri);
+				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				if (tri == kNoHit) break;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
 				uint32_t mi = __float_as_uint(r3.x);
@@ -690,8 +700,8 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			hdr.max_edge = bvh.max_edge;
 		}
 	}
-	std::memcpy(base, &hdr, sizeof(hdr));
 	float* tr = (float*)(base + hdr.tri_offset);
+	double max_edge_product = 0.0;               // max |e0|*|e1|: bounds every determinant of ray_triangle (|d| <= 2^20)
 	for (uint32_t k = 0; k < n_triangles; k++) {
 		const pt_triangle& t = triangles[k];
 		const pt_float4 &v0 = vertices[t.vertexIdx0].position, &v1 = vertices[t.vertexIdx1].position, &v2 = vertices[t.vertexIdx2].position;
@@ -705,7 +715,12 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 		r[8] = e1z; r[9] = nx; r[10] = ny; r[11] = nz;
 		uint32_t m = t.materialIdx; std::memcpy(&r[12], &m, 4);
 		r[13] = r[14] = r[15] = 0.0f;
+		double l0 = std::sqrt((double)e0x * e0x + (double)e0y * e0y + (double)e0z * e0z);
+		double l1 = std::sqrt((double)e1x * e1x + (double)e1y * e1y + (double)e1z * e1z);
+		if (!(l0 * l1 <= max_edge_product)) max_edge_product = l0 * l1;      // NaN/inf propagate and clear the flag
 	}
+	if (max_edge_product < 0x1p100) hdr.flags |= kSceneDetBounded;
+	std::memcpy(base, &hdr, sizeof(hdr));
 	float* mr = (float*)(base + hdr.mat_offset);
 	for (uint32_t k = 0; k < n_materials; k++) {
 		float* r = mr + (size_t)k * 8;
