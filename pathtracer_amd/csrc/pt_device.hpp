@@ -191,6 +191,47 @@ __device__ __forceinline__ void intersect_range(const float4* __restrict__ tris,
 	}
 }
 
+// ---- camera rays: everything that depends only on the ray ORIGIN is the same for every primary ray ----
+// All primary rays start at the camera position (kernels.cu:43), so for triangle k the reference's
+//   s = o - v0 (Functions.cuh:78), q = cross(s, e0) (:83) and dot(e1, q) (:87)
+// are the same fp32 values for every pixel and sample.  They are computed once per block (same operations,
+// same operands, hence the same bits) into LDS and the per-ray test keeps only what depends on d:
+// 27 flops instead of 45 for a full test.
+struct PrimRec { float4 a, b; };      // {s.xyz, dot(e1,q)} {q.xyz, 0}
+
+__device__ __forceinline__ void stage_primary_records(const float4* __restrict__ tris, uint32_t n, Vec3 o, float4* __restrict__ s_prim) {
+	for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
+		Vec3 v0{ r0.x, r0.y, r0.z }, e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x };
+		Vec3 s = Vec3{ o.x - v0.x, o.y - v0.y, o.z - v0.z };
+		Vec3 q = cross3(s, e0);
+		s_prim[2 * k + 0] = float4{ s.x, s.y, s.z, dot3(e1, q) };
+		s_prim[2 * k + 1] = float4{ q.x, q.y, q.z, 0.0f };
+	}
+}
+
+// intersect_range for rays from the camera position; best_t / hit_tri as there
+__device__ __forceinline__ void intersect_range_primary(const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t n,
+                                                        bool det_bounded, Vec3 d, float& best_t, uint32_t& hit_tri) {
+	for (uint32_t k = 0; k < n; k++) {
+		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
+		Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x };
+		Vec3 h = cross3(d, e1);
+		float det = dot3(e0, h);
+		if (det < kEpsilon) continue;                 // Functions.cuh:72
+		float f;                                      // :77
+		if (det_bounded) f = rcp_newton(det); else f = 1.0f / det;
+		float4 pa = prim[2 * k + 0];
+		float u = f * dot3(Vec3{ pa.x, pa.y, pa.z }, h);   // :80
+		if (u < 0.0f || u > 1.0f) continue;
+		float4 pb = prim[2 * k + 1];
+		float v = f * dot3(d, Vec3{ pb.x, pb.y, pb.z });   // :84
+		if (v < 0.0f || u + v > 1.0f) continue;
+		float t = f * pa.w;                           // :87
+		if (t > kEpsilon && t < best_t) { best_t = t; hit_tri = k; }   // kernels.cu:64
+	}
+}
+
 // ---- BVH traversal (pt_bvh.hpp): same answer as intersect_range over all triangles ----
 struct BvhView {
 	const float4* nodes;     // 4 float4 per node

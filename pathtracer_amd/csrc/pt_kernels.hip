@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -35,6 +36,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kLdsTriChunk = 1024;                 // 64 KiB of packed triangles per stage
 constexpr uint32_t kShadeLdsMaxTris = 1536;             // shade keeps triangles + materials in LDS up to here
 constexpr uint32_t kShadeLdsMaxMats = 256;
+constexpr uint32_t kPrimMaxTris = 1024;                 // camera-ray constants (PrimRec, 32 B per triangle) are staged in LDS up to here
 
 __device__ const JumpTable g_jump = make_jump_table();
 constexpr JumpTable h_jump = make_jump_table();
@@ -396,6 +398,8 @@ __global__ __launch_bounds__(kBlock) void k_fill_f32(float* __restrict__ dst, fl
 
 // Fused engine: one lane per pixel, samples in order, all path state in registers.
 // SCENE: 0 = brute force, wave-uniform reads through the scalar cache; 1 = brute force from LDS; 2 = BVH
+// (tried and dropped: the reference's 4 triangles held in SGPRs across the pixel loop with the triangle loop
+// unrolled -- 22 SGPR spills, 169 vs 174 Grays/s)
 template <bool STRIDED, int SCENE>
 __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
@@ -413,12 +417,16 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 	if (BVH) bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
 	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const float4* mats = tris + (size_t)n_tris * 4;
+	float4* s_prim = s_scene;                     // camera-ray constants (brute-force modes): 2 float4 per triangle
 	if (SCENE_LDS) {
 		uint32_t nt4 = n_tris * 4, nm2 = n_mats * 2;
 		for (uint32_t k = threadIdx.x; k < nt4; k += kBlock) s_scene[k] = tris[k];
 		for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = mats[k];
-		tris = s_scene; mats = s_scene + nt4;
+		s_prim = s_scene + nt4 + nm2;
 	}
+	const bool use_prim = !BVH && n_tris <= kPrimMaxTris;
+	if (use_prim) stage_primary_records(tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_prim);
+	if (SCENE_LDS) { tris = s_scene; mats = s_scene + n_tris * 4; }
 	__syncthreads();
 	uint32_t n_rays = 0, n_diffuse = 0;
 	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < f.pixel_count; li += gridDim.x * kBlock) {
@@ -439,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 				n_rays++;
 				uint32_t tri = kNoHit;
 				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+				else if (b == 0 && use_prim) intersect_range_primary(tris, s_prim, n_tris, det_bounded, d, best, tri);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				if (tri == kNoHit) break;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
@@ -889,10 +898,12 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 		host_jump_matrix((uint64_t)frame_first * frame->stride, first.cols);
 		host_jump_matrix(frame->stride, per.cols);
 	}
-	// scene access: up to 32 triangles the wave-uniform reads go through the scalar cache (s_load,
-	// +3.5 % measured on the default scene), up to kBvhMinTris brute force from LDS, above that the BVH
-	int mode = scene_has_bvh(si) ? 2 : (si.n_tris > 32 && shade_scene_in_lds(si)) ? 1 : 0;
-	size_t lds_bytes = mode == 1 ? shade_lds_bytes(si) : 0;
+	// scene access: brute force from LDS while the scene fits (ds_read broadcasts into VGPRs: plain VGPR-operand VALU
+	// runs at 2.4 cycles/instruction, an SGPR operand halves that -- tools/valu_microbench.hip), through the scalar
+	// cache when it does not, above kBvhMinTris the BVH.  Measured on the default scene: LDS 208, scalar 202 Grays/s.
+	int mode = scene_has_bvh(si) ? 2 : shade_scene_in_lds(si) ? 1 : 0;
+	if (const char* e = getenv("PT_FUSED_MODE")) { int m = atoi(e); if (m == 1 && shade_scene_in_lds(si)) mode = 1; else if (m == 0 && !scene_has_bvh(si)) mode = 0; }
+	size_t lds_bytes = (mode == 1 ? shade_lds_bytes(si) : 0) + (mode != 2 && si.n_tris <= kPrimMaxTris ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
 	// One lane per pixel, every block its own 256 pixels: measured on MI355X (1080p, 64 spp) the
 	// hardware scheduler back-filling 8100 short-lived blocks beats any persistent grid-stride
 	// grid (145 vs 131 Grays/s at 8 blocks/CU) because the kernel holds 77 VGPRs = 6 waves/SIMD and a
