@@ -104,6 +104,12 @@ int pt_readback_rng(pt_handle* h, uint32_t* states, size_t n);
 /* Device-to-device copy of the running mean into caller-owned device memory (n_floats = 4 * pixel_count);
  * returns when the copy is complete.  The snapshot collectives work on while the next samples render. */
 int pt_copy_mean(pt_handle* h, void* device_dst, size_t n_floats);
+/* The same copy, only ENQUEUED on the plugin's stream behind whatever is in flight there (also between
+ * BeginDrawing and FinalizeDrawing: the snapshot then holds the frame being drawn); nothing is awaited. */
+int pt_copy_mean_async(pt_handle* h, void* device_dst, size_t n_floats);
+/* The plugin's HIP stream (a hipStream_t), for callers that order their own device work against the
+ * frames with events -- the reference runs everything on the default stream (PathTracer.cu:116-152). */
+void* pt_stream(pt_handle* h);
 /* Device address of the running mean (float4 x pixel_count), for collectives and zero-copy. */
 void* pt_device_mean(pt_handle* h);
 int pt_get_stats(pt_handle* h, pt_stats* out);

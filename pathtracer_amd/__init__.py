@@ -108,6 +108,8 @@ SYMBOLS = {
     "pt_readback": (C.c_int, [_VP, _VP, _SZ]),
     "pt_readback_rng": (C.c_int, [_VP, _VP, _SZ]),
     "pt_copy_mean": (C.c_int, [_VP, _VP, _SZ]),
+    "pt_copy_mean_async": (C.c_int, [_VP, _VP, _SZ]),
+    "pt_stream": (_VP, [_VP]),
     "pt_device_mean": (_VP, [_VP]),
     "pt_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
     "pt_get_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), _U32P, _U32P]),
@@ -315,6 +317,14 @@ class PathTracer:
     def copy_mean(self, device_ptr: int, n_floats: int) -> None:
         """Snapshot of the running mean into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
         _check(self._lib.pt_copy_mean(self._h, C.c_void_p(int(device_ptr)), int(n_floats)), self._lib, "pt_copy_mean")
+
+    def copy_mean_async(self, device_ptr: int, n_floats: int) -> None:
+        """The same copy enqueued on the plugin's stream behind the frame in flight; nothing is awaited."""
+        _check(self._lib.pt_copy_mean_async(self._h, C.c_void_p(int(device_ptr)), int(n_floats)), self._lib, "pt_copy_mean_async")
+
+    def stream(self) -> int:
+        """The plugin's hipStream_t as an integer (torch.cuda.ExternalStream(tracer.stream()))."""
+        return int(self._lib.pt_stream(self._h) or 0)
 
     def device_mean(self) -> int:
         return int(self._lib.pt_device_mean(self._h) or 0)

@@ -75,6 +75,18 @@ __device__ __forceinline__ uint32_t mat_apply(const uint32_t* __restrict__ cols,
 	return y;
 }
 
+// The same product with the matrix in LDS, for uses that are rare (once per pixel, or a branch that is almost never
+// taken): volatile, rolled reads so that the compiler does not park the 32 columns in VGPRs across the hot loops.
+__device__ __forceinline__ uint32_t mat_apply_lds(const volatile uint32_t* cols, uint32_t x) {
+	uint32_t y = 0;
+#pragma unroll 1
+	for (int b = 0; b < 32; b += 4) {
+		uint32_t c0 = cols[b], c1 = cols[b + 1], c2 = cols[b + 2], c3 = cols[b + 3];
+		y ^= (c0 & (0u - ((x >> b) & 1u))) ^ (c1 & (0u - ((x >> (b + 1)) & 1u))) ^ (c2 & (0u - ((x >> (b + 2)) & 1u))) ^ (c3 & (0u - ((x >> (b + 3)) & 1u)));
+	}
+	return y;
+}
+
 // Functions.cuh:45 : (float)x / (uint)-1.  (uint)-1 converts to 2^32, so this is an exact scale.
 __device__ __forceinline__ float rng_uniform(uint32_t& s) {
 	s = xs_step(s);

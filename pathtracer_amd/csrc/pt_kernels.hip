@@ -95,15 +95,31 @@ int check_frame(const pt_frame* f) {
 	return PT_OK;
 }
 
-// step^k as a matrix (host): cols[b] = step^k(1<<b), k reduced modulo the period 2^32-1.
+// step^k as a matrix (host): cols[b] = step^k(1<<b), k reduced modulo the period 2^32-1.  This runs on the host in
+// front of every strided launch, so step^(2^j) is applied through byte tables (4 lookups, not a 32-step loop): ~2 us
+// per matrix instead of ~40, which was a visible gap between back-to-back 1.3 ms launches.
+struct HostJumpBytes { uint32_t t[32][4][256]; };
+const HostJumpBytes& host_jump_bytes() {
+	static const HostJumpBytes* tables = [] {
+		HostJumpBytes* h = new HostJumpBytes;
+		for (int j = 0; j < 32; j++)
+			for (int q = 0; q < 4; q++)
+				for (uint32_t v = 0; v < 256; v++) h->t[j][q][v] = mat_apply_cx(h_jump.cols[j], v << (8 * q));
+		return h;
+	}();
+	return *tables;
+}
 void host_jump_matrix(uint64_t k, uint32_t cols[32]) {
 	k %= 0xFFFFFFFFull;
-	for (int b = 0; b < 32; b++) {
-		uint32_t x = 1u << b;
-		uint64_t kk = k;
-		for (int j = 0; kk; j++, kk >>= 1)
-			if (kk & 1u) x = mat_apply_cx(h_jump.cols[j], x);
-		cols[b] = x;
+	const HostJumpBytes& hb = host_jump_bytes();
+	for (int b = 0; b < 32; b++) cols[b] = 1u << b;
+	for (int j = 0; k; j++, k >>= 1) {
+		if (!(k & 1u)) continue;
+		const auto& t = hb.t[j];
+		for (int b = 0; b < 32; b++) {
+			uint32_t x = cols[b];
+			cols[b] = t[0][x & 255u] ^ t[1][(x >> 8) & 255u] ^ t[2][(x >> 16) & 255u] ^ t[3][x >> 24];
+		}
 	}
 }
 
@@ -411,6 +427,10 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_stack[BVH ? kBvhStackDepth * kBlock : 1];
+	// STRIDED: the two jump matrices are read from LDS, not kept in 64 SGPRs across the pixel loop (106 SGPRs admit
+	// 6 blocks per CU, 74 admit 8)
+	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1];
+	if (STRIDED && threadIdx.x < 32) { s_first[threadIdx.x] = first.cols[threadIdx.x]; s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x]; }
 	stage_jump31(s_jump);
 	const bool det_bounded = scene_det_bounded(scene);
 	BvhView bv{};
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 		uint32_t i = f.pixel_first + li;
 		uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
 		uint32_t start = rng_io[li];
-		if (STRIDED) start = mat_apply(first.cols, start);
+		if (STRIDED) start = mat_apply_lds(s_first, start);
 		uint32_t rng = start;
 		float4 m = mean_io[li];
 		for (uint32_t s = 0; s < n_samples; s++) {
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 			if (STRIDED) {
 				// next sample starts at step^stride(start); when this sample drew exactly `stride`
 				// numbers (always, at stride 35 on the default scene) that is the state we are in
-				if (draws != f.stride) rng = mat_apply(per_sample.cols, start);
+				if (draws != f.stride) rng = mat_apply_lds(s_per_sample, start);
 				start = rng;
 			}
 		}
@@ -902,7 +922,6 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	// runs at 2.4 cycles/instruction, an SGPR operand halves that -- tools/valu_microbench.hip), through the scalar
 	// cache when it does not, above kBvhMinTris the BVH.  Measured on the default scene: LDS 208, scalar 202 Grays/s.
 	int mode = scene_has_bvh(si) ? 2 : shade_scene_in_lds(si) ? 1 : 0;
-	if (const char* e = getenv("PT_FUSED_MODE")) { int m = atoi(e); if (m == 1 && shade_scene_in_lds(si)) mode = 1; else if (m == 0 && !scene_has_bvh(si)) mode = 0; }
 	size_t lds_bytes = (mode == 1 ? shade_lds_bytes(si) : 0) + (mode != 2 && si.n_tris <= kPrimMaxTris ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
 	// One lane per pixel, every block its own 256 pixels: measured on MI355X (1080p, 64 spp) the
 	// hardware scheduler back-filling 8100 short-lived blocks beats any persistent grid-stride

@@ -242,6 +242,14 @@ public:
 		PT_TRY(pt_hip_stream_synchronize(_stream));
 		return PT_OK;
 	}
+	int CopyMeanAsync(void* device_dst, size_t n_floats) {
+		if (_error) return _error;
+		if (!device_dst) return plugin_fail(PT_ERR_INVALID, "copy_mean_async: null pointer");
+		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "copy_mean_async: n_floats must be 4 * pixel_count");
+		PT_TRY(pt_hip_memcpy_d2d(device_dst, _dev.mean, n_floats * sizeof(float), _stream));
+		return PT_OK;
+	}
+	void* Stream() const { return _stream; }
 	void* DeviceMean() { if (_drawState == Drawing) FinalizeDrawing(); return _dev.mean; }
 
 	int Stats(pt_stats* out) {
@@ -426,6 +434,8 @@ int pt_render(pt_handle* h, uint32_t spp) { PT_HANDLE(h); return tracer->Render(
 int pt_readback(pt_handle* h, float* rgba, size_t n_floats) { PT_HANDLE(h); return tracer->Readback(rgba, n_floats); }
 int pt_readback_rng(pt_handle* h, uint32_t* states, size_t n) { PT_HANDLE(h); return tracer->ReadbackRng(states, n); }
 int pt_copy_mean(pt_handle* h, void* device_dst, size_t n_floats) { PT_HANDLE(h); return tracer->CopyMean(device_dst, n_floats); }
+int pt_copy_mean_async(pt_handle* h, void* device_dst, size_t n_floats) { PT_HANDLE(h); return tracer->CopyMeanAsync(device_dst, n_floats); }
+void* pt_stream(pt_handle* h) { return h ? as_tracer(h)->Stream() : nullptr; }
 void* pt_device_mean(pt_handle* h) { return h ? as_tracer(h)->DeviceMean() : nullptr; }
 int pt_get_stats(pt_handle* h, pt_stats* out) {
 	PT_HANDLE(h);

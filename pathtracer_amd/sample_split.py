@@ -20,7 +20,7 @@ def shard_samples(samples_per_rank: int, rank: int) -> int:
     return rank * samples_per_rank
 
 
-def exchange_and_combine(mean, dist, combine_slices: Callable, out=None, scratch=None):
+def exchange_and_combine(mean, dist, combine_slices: Callable, out=None, scratch=None, slice_out=None):
     """mean: flat float32 tensor (4 * n_pixels) holding this rank's running mean.
 
     combine_slices(stacked, shards, n_pixels_in_slice, out_slice): fixed-order tree over
@@ -42,7 +42,7 @@ def exchange_and_combine(mean, dist, combine_slices: Callable, out=None, scratch
             stacked[r * slice_floats:(r + 1) * slice_floats] = gathered[r][rank * slice_floats:(rank + 1) * slice_floats]
     else:
         dist.all_to_all_single(stacked, mean)               # slice j of every rank's mean -> rank j, shard-major
-    my_slice = torch.empty(slice_floats, dtype=mean.dtype, device=mean.device)
+    my_slice = slice_out if slice_out is not None else torch.empty(slice_floats, dtype=mean.dtype, device=mean.device)
     combine_slices(stacked, world, slice_floats // 4, my_slice)
     image = out if out is not None else torch.empty(n, dtype=mean.dtype, device=mean.device)
     dist.all_gather_into_tensor(image, my_slice) if dist.get_backend() != "gloo" else _gloo_all_gather(dist, image, my_slice, world)
