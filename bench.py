@@ -32,6 +32,9 @@ import numpy as np
 
 WIDTH, HEIGHT, SPP_PER_STEP, DEPTH = 1920, 1080, 64, 10
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles per SIMD at 2.4 GHz (same guide: v_fma_f32
+# 2 cycles on the SIMD-32; tools/valu_microbench.hip measures 2.4-2.6 at the clock the chip holds under load)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 # SURVEY 8d algorithmic traffic of the wavefront formulation per pixel-sample on the default
 # scene: generate 52 + extend 36 + shade-diffuse 104 + extend 36 + shade-emissive 44*p +
 # accumulate 48 = 276 + 44 p bytes for 2 rays; p = share of secondary rays that reach the light
@@ -192,13 +195,15 @@ def main():
     if rank == 0:
         rays_per_launch = rays_rank / max(1, args.steps)
         achieved = rays_per_launch * BYTES_PER_RAY / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0
-        traffic = None
+        traffic = valu_insts = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{args.engine}_{w}x{h}_{SPP_PER_STEP}spp")
+                pmc = json.load(open(tpath))
+                traffic = pmc.get(f"{args.engine}_{w}x{h}_{SPP_PER_STEP}spp")
+                valu_insts = pmc.get(f"{args.engine}_{w}x{h}_{SPP_PER_STEP}spp_valu_insts")
             except Exception:
-                traffic = None
+                traffic = valu_insts = None
         out = {
             "metric": "Mrays/s (primary+bounce)",
             "value": round(rays_total / dt / 1e6, 1),
@@ -218,6 +223,12 @@ def main():
                          "kernel_ms": round(last_ms, 4), "algorithmic_bytes_per_ray": round(BYTES_PER_RAY, 2),
                          "rays_per_launch": int(rays_per_launch)},
         }
+        if valu_insts and last_ms > 0:
+            # the fused kernel moves 0.3 B per ray, so the HBM figure above only says that the wavefront formulation's
+            # traffic is gone; what bounds it is VALU issue: wave64 instructions per launch (PMC, profiles/) / launch time
+            ginst = valu_insts / (last_ms * 1e-3) / 1e9
+            out["roofline_valu"] = {"bound": "valu", "achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave64-instructions/s",
+                                    "frac": round(ginst / VALU_PEAK_GINST, 4), "instructions_per_launch": valu_insts}
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp)
         else:
