@@ -50,6 +50,12 @@ enum { PT_MAT_DIFFUSE = 0, PT_MAT_REFLECTIVE = 1, PT_MAT_EMISSIVE = 2 };
  * over GPUs; with stride 35 it equals SEQUENTIAL on the default scene (35 draws per sample). */
 enum { PT_RNG_SEQUENTIAL = 0, PT_RNG_STRIDED = 1 };
 
+/* Shading.  REFERENCE = the reference's Intersect kernel (kernels.cu:71-94: REFLECTIVE absorbs, cube sampler, hit
+ * distance carried across bounces).  EXTENDED (opt-in, no reference counterpart; defined by
+ * oracle/pt_oracle.c pto_stage_shade_extended): every bounce finds its own closest hit, REFLECTIVE mirrors with
+ * throughput reflectivity*color, DIFFUSE samples the cosine-weighted hemisphere (2 draws, throughput = color). */
+enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
+
 /* Which kernels execute a render call. */
 enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1 };
 
@@ -67,6 +73,8 @@ typedef struct {
     uint32_t  seed;
     uint32_t  rng_mode;
     uint32_t  stride;                    /* STRIDED only */
+    uint32_t  shading;                   /* PT_SHADING_REFERENCE (default) or PT_SHADING_EXTENDED */
+    uint32_t  _reserved[3];              /* zero */
     pt_float4 origin, top_left, bottom_left, bottom_right;  /* Camera.h:49-77 */
 } pt_frame;
 

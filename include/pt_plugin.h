@@ -49,7 +49,7 @@ typedef struct {
     uint32_t pixel_first;        /* tile split: first pixel index rendered by this instance */
     uint32_t pixel_count;        /* 0 = the whole image */
     uint32_t sample_offset;      /* STRIDED sample split: RNG index of this instance's first sample */
-    uint32_t _reserved;
+    uint32_t shading;            /* PT_SHADING_REFERENCE (default) or PT_SHADING_EXTENDED (pt_hip.h) */
 } pt_options;
 
 typedef struct {

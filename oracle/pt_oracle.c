@@ -308,6 +308,73 @@ void pto_stage_shade(pto_path *path, const pto_material *mats)
     }
 }
 
+/* ------------------------------------------------------------------ EXTENDED shading (opt-in)
+ * No reference counterpart: this is the project's own definition, written with + - * / sqrt only and a fixed
+ * operation order so that the GPU restatement (pt_device.hpp, shade_extended) is bit-identical.  "Parity" for this
+ * mode means GPU == this function; nothing in the reference pins it. */
+
+/* cos and sin of 2*pi*u, u in [0,1]: quadrant k = floor(4u), angle a = (4u - k) * pi/2 in [0, pi/2), Taylor
+ * polynomials in Horner form (error < 4e-6, ample for a direction sampler), then the quadrant's rotation. */
+void pto_sincos_turn(float u, float *c, float *s)
+{
+    float q = u * 4.0f;                       /* exact */
+    int k = (int)q;                           /* 0..4 */
+    float a = (q - (float)k) * 1.5707963267948966f;
+    float a2 = a * a;
+    float sn = a * (1.0f + a2 * (-0.16666667f + a2 * (0.0083333338f + a2 * (-0.00019841270f + a2 * 0.0000027557319f))));
+    float cs = 1.0f + a2 * (-0.5f + a2 * (0.041666668f + a2 * (-0.0013888889f + a2 * (0.000024801587f + a2 * -0.00000027557319f))));
+    switch (k & 3) {
+    case 0: *c = cs; *s = sn; break;
+    case 1: *c = -sn; *s = cs; break;
+    case 2: *c = -cs; *s = -sn; break;
+    default: *c = sn; *s = -cs; break;
+    }
+}
+
+static inline float dot3(pto_f4 a, pto_f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+void pto_stage_shade_extended(pto_path *path, const pto_material *mats)
+{
+    if (!path->alive) return;
+    const pto_material *mat = &mats[path->materialIdx];
+    pto_f4 n = path->normal, d = path->direction;
+    if (mat->type == PTO_EMISSIVE) {
+        path->frame = mul4(path->step, mat->color);
+        path->alive = 0;
+        return;
+    }
+    pto_f4 r;
+    if (mat->type == PTO_DIFFUSE) {
+        /* cosine-weighted hemisphere around the unit normal (Malley: uniform disk lifted to the hemisphere);
+         * 2 draws, radius first; throughput = albedo (cosine and pdf cancel) */
+        float u1 = pto_rng_uniform(&path->rng);
+        float u2 = pto_rng_uniform(&path->rng);
+        path->draws += 2;
+        float inv = 1.0f / sqrtf(dot3(n, n));
+        float nx = n.x * inv, ny = n.y * inv, nz = n.z * inv;
+        /* branchless orthonormal basis (Duff et al. 2017) */
+        float sg = nz >= 0.0f ? 1.0f : -1.0f;
+        float aa = -1.0f / (sg + nz);
+        float bb = nx * ny * aa;
+        float t1x = 1.0f + sg * nx * nx * aa, t1y = sg * bb, t1z = -sg * nx;
+        float t2x = bb, t2y = sg + ny * ny * aa, t2z = -ny;
+        float rad = sqrtf(u1), c, s;
+        pto_sincos_turn(u2, &c, &s);
+        float x = rad * c, y = rad * s, z = sqrtf(1.0f - u1);
+        r = f4(t1x * x + t2x * y + nx * z, t1y * x + t2y * y + ny * z, t1z * x + t2z * y + nz * z, 0.0f);
+        path->step = mul4(path->step, mat->color);
+    } else {
+        /* REFLECTIVE: mirror about the (un-normalised) geometric normal; throughput = reflectivity * color */
+        float k = (2.0f * dot3(d, n)) / dot3(n, n);
+        r = f4(d.x - k * n.x, d.y - k * n.y, d.z - k * n.z, 0.0f);
+        path->step = mul4(path->step, mul4s(mat->color, mat->reflectivity));
+    }
+    /* the reference's own ray update (kernels.cu:81-82), xyz lanes */
+    path->origin = f4(path->origin.x + (d.x * path->t + r.x * PTO_EPSILON), path->origin.y + (d.y * path->t + r.y * PTO_EPSILON),
+                      path->origin.z + (d.z * path->t + r.z * PTO_EPSILON), path->origin.w);
+    path->direction = r;
+}
+
 /* kernels.cu:17-18 */
 pto_f4 pto_accumulate(pto_f4 color, pto_f4 previousColor, uint32_t frameNumber)
 {
@@ -329,7 +396,7 @@ int pto_render(const pto_render_params *p,
                const uint32_t *pixel_ids, uint32_t pixel_first, uint32_t n,
                uint32_t *rng_states, pto_f4 *mean, pto_f4 *last_frame, pto_stats *stats)
 {
-    if (!p || !mean || p->width <= 0 || p->height <= 0 || p->depth > 32) return -1;
+    if (!p || !mean || p->width <= 0 || p->height <= 0 || p->depth > 32 || p->shading > PTO_SHADING_EXTENDED) return -1;
     if (p->rng_mode == PTO_RNG_SEQUENTIAL && !rng_states) return -2;
     for (uint32_t k = 0; k < n_tris; k++) {
         if (tris[k].vertexIdx0 >= n_verts || tris[k].vertexIdx1 >= n_verts || tris[k].vertexIdx2 >= n_verts) return -3;
@@ -362,6 +429,12 @@ int pto_render(const pto_render_params *p,
                 for (uint32_t b = 0; b < p->depth; b++) {              /* PathTracer.cu:129 */
                     if (!path.alive) break;
                     per_bounce[b] = 1;
+                    if (p->shading == PTO_SHADING_EXTENDED) {
+                        path.t = FLT_MAX;                              /* every bounce finds its own closest hit */
+                        pto_stage_extend(&path, tris, n_tris, verts);
+                        pto_stage_shade_extended(&path, mats);
+                        continue;
+                    }
                     pto_stage_extend(&path, tris, n_tris, verts);      /* :131 */
                     pto_stage_shade(&path, mats);                      /* :141 */
                 }

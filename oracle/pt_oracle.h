@@ -53,6 +53,10 @@ typedef struct {
 
 enum { PTO_DIFFUSE = 0, PTO_REFLECTIVE = 1, PTO_EMISSIVE = 2 };
 enum { PTO_RNG_SEQUENTIAL = 0, PTO_RNG_STRIDED = 1 };
+/* SURVEY 8f-4, opt-in, NOT in the reference (its REFLECTIVE absorbs, kernels.cu:91-93; its sampler is the biased cube
+ * sampler its author flags at Functions.cuh:92-96).  EXTENDED is this project's own definition (pto_stage_shade_extended):
+ * every bounce finds its own closest hit, REFLECTIVE mirrors, DIFFUSE samples the cosine-weighted hemisphere. */
+enum { PTO_SHADING_REFERENCE = 0, PTO_SHADING_EXTENDED = 1 };
 
 /* One path's state between wavefront stages (used by the per-stage parity tests). */
 typedef struct {
@@ -80,6 +84,7 @@ typedef struct {
     uint32_t spp;          /* samples to add */
     pto_f4   origin, top_left, bottom_left, bottom_right; /* Camera.h:49-77 */
     int32_t  threads;      /* OpenMP threads, <=0: default */
+    uint32_t shading;      /* PTO_SHADING_REFERENCE (0, everything above) or PTO_SHADING_EXTENDED */
 } pto_render_params;
 
 typedef struct {
@@ -102,6 +107,10 @@ void     pto_rng_seed_pixels(uint32_t seed, const uint32_t *pixel_ids, uint32_t 
 void pto_camera_default(pto_camera *cam);
 /* out[0]=position, out[1]=topLeft, out[2]=bottomLeft, out[3]=bottomRight */
 void pto_camera_corners(const pto_camera *cam, float aspect, pto_f4 out[4]);
+
+/* ---- EXTENDED shading (no reference counterpart; the GPU kernels restate exactly these operations) ---- */
+void pto_sincos_turn(float u, float *c, float *s);   /* cos, sin of 2*pi*u by quadrant + fixed polynomials, + - * only */
+void pto_stage_shade_extended(pto_path *path, const pto_material *mats);
 
 /* ---- Scene (PathTracer.cu:48-69) ---- */
 void pto_default_scene(pto_vertex v[8], pto_triangle t[4], pto_material m[2]);

@@ -51,7 +51,8 @@ class Path(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_uint32), ("seed", C.c_uint32),
                 ("rng_mode", C.c_uint32), ("stride", C.c_uint32), ("frame_first", C.c_uint32), ("spp", C.c_uint32),
-                ("origin", F4), ("top_left", F4), ("bottom_left", F4), ("bottom_right", F4), ("threads", C.c_int32)]
+                ("origin", F4), ("top_left", F4), ("bottom_left", F4), ("bottom_right", F4), ("threads", C.c_int32),
+                ("shading", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -141,16 +142,21 @@ def make_scene(vertices, triangles, materials):
     for k, tri in enumerate(triangles):
         t[k] = Triangle(*[int(c) for c in tri])
     m = (Material * len(materials))()
-    for k, (ty, col) in enumerate(materials):
-        m[k].type = int(ty)
-        m[k].color = F4(*[float(c) for c in col])
+    for k, mat in enumerate(materials):
+        m[k].type = int(mat[0])
+        m[k].color = F4(*[float(c) for c in mat[1]])
+        m[k].reflectivity = float(mat[2]) if len(mat) > 2 else 0.0
     return v, t, m
 
 
-def params(width, height, cam=None, depth=10, seed=1337, rng_mode=RNG_SEQUENTIAL, stride=35, frame_first=0, spp=1, threads=0):
+SHADING_REFERENCE, SHADING_EXTENDED = 0, 1
+
+
+def params(width, height, cam=None, depth=10, seed=1337, rng_mode=RNG_SEQUENTIAL, stride=35, frame_first=0, spp=1, threads=0,
+           shading=SHADING_REFERENCE):
     cam = cam or default_camera()
     c = camera_corners(cam, np.float32(width) / np.float32(height))
-    return RenderParams(width, height, depth, seed, rng_mode, stride, frame_first, spp, c[0], c[1], c[2], c[3], threads)
+    return RenderParams(width, height, depth, seed, rng_mode, stride, frame_first, spp, c[0], c[1], c[2], c[3], threads, shading)
 
 
 def seed_states(seed, n, pixel_first=0, pixel_ids=None) -> np.ndarray:

@@ -23,6 +23,7 @@ PT_OK = 0
 PT_RNG_SEQUENTIAL, PT_RNG_STRIDED = 0, 1
 PT_ENGINE_WAVEFRONT, PT_ENGINE_FUSED = 0, 1
 PT_MAT_DIFFUSE, PT_MAT_REFLECTIVE, PT_MAT_EMISSIVE = 0, 1, 2
+PT_SHADING_REFERENCE, PT_SHADING_EXTENDED = 0, 1
 PT_MAX_DEPTH = 32
 PT_STATS_WORDS = 4 + PT_MAX_DEPTH
 
@@ -61,6 +62,7 @@ class CameraData(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
                 ("depth", C.c_uint32), ("seed", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32),
+                ("shading", C.c_uint32), ("_reserved", C.c_uint32 * 3),
                 ("origin", Float4), ("top_left", Float4), ("bottom_left", Float4), ("bottom_right", Float4)]
 
 
@@ -72,7 +74,7 @@ class Options(C.Structure):
     _fields_ = [("engine", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32), ("depth", C.c_uint32),
                 ("seed", C.c_uint32), ("samples_per_begin", C.c_uint32), ("samples_per_pass", C.c_uint32),
                 ("device", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
-                ("sample_offset", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("sample_offset", C.c_uint32), ("shading", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -182,7 +184,7 @@ def default_scene():
 
 
 def make_scene(vertices, triangles, materials):
-    """vertices: (x,y,z,w); triangles: (i0,i1,i2,material); materials: (type,(r,g,b,a))."""
+    """vertices: (x,y,z,w); triangles: (i0,i1,i2,material); materials: (type,(r,g,b,a)[,reflectivity])."""
     v = (Vertex * len(vertices))()
     for k, p in enumerate(vertices):
         v[k].position = Float4(*[float(c) for c in p])
@@ -190,9 +192,10 @@ def make_scene(vertices, triangles, materials):
     for k, tri in enumerate(triangles):
         t[k] = Triangle(*[int(c) for c in tri])
     m = (Material * len(materials))()
-    for k, (ty, col) in enumerate(materials):
-        m[k].type = int(ty)
-        m[k].color = Float4(*[float(c) for c in col])
+    for k, mat in enumerate(materials):
+        m[k].type = int(mat[0])
+        m[k].color = Float4(*[float(c) for c in mat[1]])
+        m[k].reflectivity = float(mat[2]) if len(mat) > 2 else 0.0
     return v, t, m
 
 

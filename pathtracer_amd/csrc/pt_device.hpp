@@ -383,11 +383,59 @@ __device__ __forceinline__ void shade_diffuse(Vec3 n, float4 color, float t, con
 	step.x *= s * color.x; step.y *= s * color.y; step.z *= s * color.z; step.w *= s * color.w;
 }
 
+// ---- EXTENDED shading (opt-in; no reference counterpart) ----
+// Operation for operation what oracle/pt_oracle.c pto_stage_shade_extended / pto_sincos_turn define.
+__device__ __forceinline__ void sincos_turn(float u, float& c, float& s) {
+	float q = u * 4.0f;
+	int k = (int)q;
+	float a = (q - (float)k) * 1.5707963267948966f;
+	float a2 = a * a;
+	float sn = a * (1.0f + a2 * (-0.16666667f + a2 * (0.0083333338f + a2 * (-0.00019841270f + a2 * 0.0000027557319f))));
+	float cs = 1.0f + a2 * (-0.5f + a2 * (0.041666668f + a2 * (-0.0013888889f + a2 * (0.000024801587f + a2 * -0.00000027557319f))));
+	k &= 3;
+	c = k == 0 ? cs : k == 1 ? -sn : k == 2 ? -cs : sn;
+	s = k == 0 ? sn : k == 1 ? cs : k == 2 ? -sn : -cs;
+}
+
+// Any non-emissive hit: DIFFUSE = cosine-weighted hemisphere around the unit normal (2 draws), anything else = mirror.
+// Returns true for DIFFUSE.
+__device__ __forceinline__ bool shade_extended(uint32_t type, Vec3 n, float4 color, float reflectivity, float t,
+                                               Vec3& o, Vec3& d, float4& step, uint32_t& rng) {
+	Vec3 r;
+	bool diffuse = type == PT_MAT_DIFFUSE;
+	if (diffuse) {
+		float u1 = rng_uniform(rng);
+		float u2 = rng_uniform(rng);
+		float inv = rsqrt_ref(dot3(n, n));
+		float nx = n.x * inv, ny = n.y * inv, nz = n.z * inv;
+		float sg = nz >= 0.0f ? 1.0f : -1.0f;
+		float aa = -rcp_newton(sg + nz);               // -1.0f / (sg + nz); |sg + nz| is in [1, 2]
+		float bb = nx * ny * aa;
+		float t1x = 1.0f + sg * nx * nx * aa, t1y = sg * bb, t1z = -sg * nx;
+		float t2x = bb, t2y = sg + ny * ny * aa, t2z = -ny;
+		float rad = sqrt_fixup(u1), c, s;               // u1 >= 2^-32
+		sincos_turn(u2, c, s);
+		float x = rad * c, y = rad * s, z = sqrt_ieee(1.0f - u1);
+		r = Vec3{ t1x * x + t2x * y + nx * z, t1y * x + t2y * y + ny * z, t1z * x + t2z * y + nz * z };
+		step.x *= color.x; step.y *= color.y; step.z *= color.z; step.w *= color.w;
+	} else {
+		float k = (2.0f * dot3(d, n)) / dot3(n, n);
+		r = Vec3{ d.x - k * n.x, d.y - k * n.y, d.z - k * n.z };
+		step.x *= color.x * reflectivity; step.y *= color.y * reflectivity; step.z *= color.z * reflectivity; step.w *= color.w * reflectivity;
+	}
+	o.x = o.x + (d.x * t + r.x * kEpsilon);
+	o.y = o.y + (d.y * t + r.y * kEpsilon);
+	o.z = o.z + (d.z * t + r.z * kEpsilon);
+	d = r;
+	return diffuse;
+}
+
 // InitializeRays' ray set-up, kernels.cu:36-44, all four lanes of the screen point.
 struct FrameDev {
 	int32_t  width, height;
 	uint32_t pixel_first, pixel_count;
 	uint32_t depth, seed, rng_mode, stride;
+	uint32_t shading;
 	float4   origin, top_left, bottom_left, bottom_right;
 };
 

@@ -75,7 +75,7 @@ FrameDev to_dev(const pt_frame& f) {
 	FrameDev d;
 	d.width = f.width; d.height = f.height;
 	d.pixel_first = f.pixel_first; d.pixel_count = f.pixel_count;
-	d.depth = f.depth; d.seed = f.seed; d.rng_mode = f.rng_mode; d.stride = f.stride;
+	d.depth = f.depth; d.seed = f.seed; d.rng_mode = f.rng_mode; d.stride = f.stride; d.shading = f.shading;
 	d.origin = float4{ f.origin.x, f.origin.y, f.origin.z, f.origin.w };
 	d.top_left = float4{ f.top_left.x, f.top_left.y, f.top_left.z, f.top_left.w };
 	d.bottom_left = float4{ f.bottom_left.x, f.bottom_left.y, f.bottom_left.z, f.bottom_left.w };
@@ -92,6 +92,7 @@ int check_frame(const pt_frame* f) {
 	if (f->depth < 1 || f->depth > PT_MAX_DEPTH) return fail(PT_ERR_INVALID, "depth must be 1..PT_MAX_DEPTH");
 	if (f->rng_mode != PT_RNG_SEQUENTIAL && f->rng_mode != PT_RNG_STRIDED) return fail(PT_ERR_INVALID, "unknown rng_mode");
 	if (f->rng_mode == PT_RNG_STRIDED && f->stride == 0) return fail(PT_ERR_INVALID, "stride must be positive in strided mode");
+	if (f->shading != PT_SHADING_REFERENCE && f->shading != PT_SHADING_EXTENDED) return fail(PT_ERR_INVALID, "unknown shading");
 	return PT_OK;
 }
 
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 	const uint32_t G = gridDim.x;
 	const uint32_t count = count_ptr[blockIdx.x];
 	const uint32_t lane = threadIdx.x & 63u;
+	const bool extended = f.shading == PT_SHADING_EXTENDED;
 	__shared__ uint32_t s_out;            // this block's survivors so far
 	if (threadIdx.x == 0) s_out = 0;
 	__syncthreads();
@@ -312,16 +314,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
 			uint32_t type = 0xFFFFFFFFu;
 			float4 color = float4{ 0, 0, 0, 0 };
+			float reflectivity = 0.0f;
 			Vec3 n{ 0, 0, 0 };
 			if (h.y != kNoHit) {
 				float4 r2 = tris[4 * h.y + 2], r3 = tris[4 * h.y + 3];
 				uint32_t m = __float_as_uint(r3.x);
-				type = __float_as_uint(mats[2 * m].x);
+				float4 head = mats[2 * m];
+				type = __float_as_uint(head.x);
+				reflectivity = head.y;
 				color = mats[2 * m + 1];
 				n = Vec3{ r2.y, r2.z, r2.w };
 			}
 			bool emitted = false;
-			if (type == PT_MAT_DIFFUSE) {
+			// REFERENCE: only DIFFUSE continues (kernels.cu:79-93); EXTENDED: every hit that is not an emitter does
+			if (type == PT_MAT_DIFFUSE || (extended && h.y != kNoHit && type != PT_MAT_EMISSIVE)) {
 				float4 b = qb[q];
 				if (FIRST) {
 					o = Vec3{ f.origin.x, f.origin.y, f.origin.z }; d = Vec3{ b.x, b.y, b.z };
@@ -332,7 +338,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 				}
 				t = __uint_as_float(h.x);
 				rng = __float_as_uint(b.w);
-				shade_diffuse(n, color, t, s_jump, o, d, step, rng);
+				if (extended) { shade_extended(type, n, color, reflectivity, t, o, d, step, rng); t = FLT_MAX; }   // the next bounce finds its own closest hit
+				else shade_diffuse(n, color, t, s_jump, o, d, step, rng);
 				cont = true;
 				if (EXTEND && !last_bounce) intersect_range(tris, 0, n_tris, det_bounded, o, d, t, next_tri);
 			} else {
@@ -445,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 		s_prim = s_scene + nt4 + nm2;
 	}
 	const bool use_prim = !BVH && n_tris <= kPrimMaxTris;
+	const bool extended = f.shading == PT_SHADING_EXTENDED;
 	if (use_prim) stage_primary_records(tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_prim);
 	if (SCENE_LDS) { tris = s_scene; mats = s_scene + n_tris * 4; }
 	__syncthreads();
@@ -466,15 +474,19 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 			for (uint32_t b = 0; b < f.depth; b++) {
 				n_rays++;
 				uint32_t tri = kNoHit;
+				if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
 				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
 				else if (b == 0 && use_prim) intersect_range_primary(tris, s_prim, n_tris, det_bounded, d, best, tri);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				if (tri == kNoHit) break;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
 				uint32_t mi = __float_as_uint(r3.x);
-				uint32_t type = __float_as_uint(mats[2 * mi].x);
+				float4 head = mats[2 * mi];
+				uint32_t type = __float_as_uint(head.x);
 				float4 color = mats[2 * mi + 1];
-				if (type == PT_MAT_DIFFUSE) {
+				if (extended && type != PT_MAT_EMISSIVE) {
+					if (shade_extended(type, Vec3{ r2.y, r2.z, r2.w }, color, head.y, best, o, d, step, rng)) { n_diffuse++; draws += 2; }
+				} else if (type == PT_MAT_DIFFUSE) {
 					shade_diffuse(Vec3{ r2.y, r2.z, r2.w }, color, best, s_jump, o, d, step, rng);
 					n_diffuse++;
 					draws += 33;
@@ -754,7 +766,8 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 	for (uint32_t k = 0; k < n_materials; k++) {
 		float* r = mr + (size_t)k * 8;
 		uint32_t type = materials[k].type; std::memcpy(&r[0], &type, 4);
-		r[1] = r[2] = r[3] = 0.0f;
+		r[1] = materials[k].reflectivity;                // read by PT_SHADING_EXTENDED only
+		r[2] = r[3] = 0.0f;
 		r[4] = materials[k].color.x; r[5] = materials[k].color.y; r[6] = materials[k].color.z; r[7] = materials[k].color.w;
 	}
 	return PT_OK;

@@ -187,6 +187,7 @@ public:
 		if (in.depth < 1 || in.depth > PT_MAX_DEPTH) return plugin_fail(PT_ERR_INVALID, "depth must be 1..32");
 		if (in.rng_mode == PT_RNG_STRIDED && in.stride == 0) return plugin_fail(PT_ERR_INVALID, "stride must be positive");
 		if (in.samples_per_begin == 0) return plugin_fail(PT_ERR_INVALID, "samples_per_begin must be positive");
+		if (in.shading != PT_SHADING_REFERENCE && in.shading != PT_SHADING_EXTENDED) return plugin_fail(PT_ERR_INVALID, "unknown shading");
 		uint64_t n = (uint64_t)_width * _height;
 		uint64_t cnt = in.pixel_count ? in.pixel_count : n - std::min<uint64_t>(in.pixel_first, n);
 		if ((uint64_t)in.pixel_first + cnt > n || cnt == 0) return plugin_fail(PT_ERR_INVALID, "pixel range exceeds the image");
@@ -277,6 +278,7 @@ private:
 		f.width = _width; f.height = _height;
 		f.pixel_first = _pixelFirst; f.pixel_count = _pixelCount;
 		f.depth = _opt.depth; f.seed = _opt.seed; f.rng_mode = _opt.rng_mode; f.stride = _opt.stride;
+		f.shading = _opt.shading;
 		f.origin = _camera.GetPosition();
 		f.top_left = _camera.GetTopLeft();
 		f.bottom_left = _camera.GetBottomLeft();

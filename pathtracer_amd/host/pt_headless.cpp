@@ -7,7 +7,7 @@
 // Program.cpp:254-298 and the resize callback :204-211), and write the running mean as a PFM image.
 //
 //   pt_headless [--plugin NAME] [--size WxH] [--frames N] [--spp-per-frame K] [--scene FILE] [--depth D]
-//               [--engine fused|wavefront] [--fov DEG] [--pos x,y,z] [--move-at F] [--resize-at F WxH]
+//               [--engine fused|wavefront] [--shading reference|extended] [--fov DEG] [--pos x,y,z] [--move-at F] [--resize-at F WxH]
 //               [--report-every N] [--out image.pfm]
 #include <chrono>
 #include <cstdio>
@@ -40,7 +40,7 @@ bool parse_size(const char* s, int& w, int& h) { return std::sscanf(s, "%dx%d", 
 } // namespace
 
 int main(int argc, char** argv) {
-	std::string plugin = "PT_HipWavefront", scene, out, engine;
+	std::string plugin = "PT_HipWavefront", scene, out, engine, shading;
 	int width = 960, height = 540;                           // the reference's window, main.cpp:5
 	int frames = 64, sppPerFrame = 1, depth = 0, moveAt = -1, resizeAt = -1, newW = 0, newH = 0, reportEvery = 0;
 	CameraData* cameraData = new CameraData();               // Program.cpp:36
@@ -53,6 +53,7 @@ int main(int argc, char** argv) {
 		else if (!std::strcmp(argv[a], "--scene")) { need(1); scene = argv[++a]; }
 		else if (!std::strcmp(argv[a], "--depth")) { need(1); depth = std::atoi(argv[++a]); }
 		else if (!std::strcmp(argv[a], "--engine")) { need(1); engine = argv[++a]; }
+		else if (!std::strcmp(argv[a], "--shading")) { need(1); shading = argv[++a]; }
 		else if (!std::strcmp(argv[a], "--fov")) { need(1); cameraData->fieldOfView = (float)std::atof(argv[++a]); }
 		else if (!std::strcmp(argv[a], "--pos")) { need(1); float x, y, z; if (std::sscanf(argv[++a], "%f,%f,%f", &x, &y, &z) != 3) { std::fprintf(stderr, "bad --pos\n"); return 2; } cameraData->position.x = x; cameraData->position.y = y; cameraData->position.z = z; }
 		else if (!std::strcmp(argv[a], "--move-at")) { need(1); moveAt = std::atoi(argv[++a]); }
@@ -86,6 +87,7 @@ int main(int argc, char** argv) {
 		if (depth > 0) o.depth = (uint32_t)depth;
 		if (sppPerFrame > 0) o.samples_per_begin = (uint32_t)sppPerFrame;
 		if (engine == "wavefront") o.engine = PT_ENGINE_WAVEFRONT; else if (engine == "fused") o.engine = PT_ENGINE_FUSED;
+		if (shading == "extended") o.shading = PT_SHADING_EXTENDED; else if (shading == "reference") o.shading = PT_SHADING_REFERENCE;
 		if (set_options(pathTracer, &o)) return fail("pt_set_options");
 	}
 

@@ -21,7 +21,7 @@ import scenes                            # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 CASES = {
-    # name: (scene fn, width, height, spp, depth, rng_mode, stride, camera kwargs)
+    # name: (scene fn, width, height, spp, depth, rng_mode, stride, camera kwargs[, shading])
     "default_64x48_4spp": ("default", 64, 48, 4, 10, po.RNG_SEQUENTIAL, 35, {}),
     "default_160x120_2spp": ("default", 160, 120, 2, 10, po.RNG_SEQUENTIAL, 35, {}),
     "default_33x17_3spp_d3": ("default", 33, 17, 3, 3, po.RNG_SEQUENTIAL, 35, {}),
@@ -30,6 +30,9 @@ CASES = {
     "synthetic200_64x48_2spp": ("synthetic200", 64, 48, 2, 10, po.RNG_SEQUENTIAL, 35, {}),
     "default_rotated_64x48_2spp": ("default", 64, 48, 2, 10, po.RNG_SEQUENTIAL, 35,
                                    {"position": (0.05, -0.02, 0.1, 1.0), "rotation": (0.0, 0.08715574, 0.0, 0.9961947), "fov": 70.0}),
+    # PT_SHADING_EXTENDED (no reference counterpart, the oracle IS the definition)
+    "extended_mirror_96x64_3spp_d16": ("mirror", 96, 64, 3, 16, po.RNG_SEQUENTIAL, 35, {}, po.SHADING_EXTENDED),
+    "extended_default_64x48_4spp_strided40": ("default", 64, 48, 4, 10, po.RNG_STRIDED, 40, {}, po.SHADING_EXTENDED),
 }
 
 
@@ -38,16 +41,19 @@ def scene_of(name):
         return scenes.default_scene()
     if name == "allmat":
         return scenes.all_materials_scene()
+    if name == "mirror":
+        return scenes.mirror_scene()
     if name == "synthetic200":
         return scenes.synthetic_scene(200)
     raise KeyError(name)
 
 
 def run_case(case):
-    scene_name, w, h, spp, depth, mode, stride, cam_kw = CASES[case]
+    scene_name, w, h, spp, depth, mode, stride, cam_kw = CASES[case][:8]
+    shading = CASES[case][8] if len(CASES[case]) > 8 else po.SHADING_REFERENCE
     V, T, M = scene_of(scene_name)
     cam = po.make_camera(**cam_kw) if cam_kw else po.default_camera()
-    p = po.params(w, h, cam=cam, depth=depth, rng_mode=mode, stride=stride, spp=spp, threads=0)
+    p = po.params(w, h, cam=cam, depth=depth, rng_mode=mode, stride=stride, spp=spp, threads=0, shading=shading)
     mean, rng, st, last = po.render(p, scene=po.make_scene(V, T, M), want_last_frame=True)
     return dict(mean=mean, rng=rng if rng is not None else np.zeros(0, np.uint32), last_frame=last,
                 rays=np.uint64(st.rays), draws=np.uint64(st.draws),

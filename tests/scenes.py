@@ -38,6 +38,12 @@ def _facing(corners, toward):
     return corners
 
 
+def mirror_scene():
+    """The all-materials scene with a working mirror (reflectivity 0.9) for PT_SHADING_EXTENDED."""
+    V, T, M = all_materials_scene()
+    return V, T, [(m[0], m[1], 0.9 if m[0] == REFLECTIVE else 0.0) for m in M]
+
+
 def all_materials_scene():
     """BASELINE.json configs[4]: every material type the reference supports -- DIFFUSE, EMISSIVE
     and REFLECTIVE (which the reference absorbs, kernels.cu:91-93) -- in a closed box around the

@@ -80,18 +80,22 @@ def _pt_scene(pt, name):
 @pytest.mark.parametrize("case", sorted(make_golden.CASES))
 def test_gpu_reproduces_golden_vectors(pt, name, engine, case):
     """The committed vectors (tests/golden, made by the oracle) -- no oracle code runs here."""
-    scene_name, w, h, spp, depth, mode, stride, cam_kw = make_golden.CASES[case]
+    scene_name, w, h, spp, depth, mode, stride, cam_kw = make_golden.CASES[case][:8]
+    shading = make_golden.CASES[case][8] if len(make_golden.CASES[case]) > 8 else 0
     want = np.load(os.path.join(GOLDEN, case + ".npz"))
     cam = pt.CameraData(cam_kw.get("position", (0, 0, 0, 1)), cam_kw.get("rotation", (0, 0, 0, 1)), cam_kw.get("fov", 90.0))
     with pt.PathTracer(w, h, camera=cam) as tr:
         tr.set_scene(*_pt_scene(pt, scene_name))
-        tr.set_options(engine=engine, depth=depth, rng_mode=mode, stride=stride, samples_per_pass=2)
+        tr.set_options(engine=engine, depth=depth, rng_mode=mode, stride=stride, samples_per_pass=2, shading=shading)
         tr.render(spp)
         img, st = tr.readback(), tr.stats()
         rng = tr.readback_rng()
     assert_bit_equal(img, want["mean"], f"{case} {name}")
     assert st.rays == int(want["rays"])
-    assert 2 * st.paths + 33 * st.diffuse_bounces == int(want["draws"])
+    if shading == 0:
+        assert 2 * st.paths + 33 * st.diffuse_bounces == int(want["draws"])
+    elif engine == 1:       # EXTENDED: 2 draws per cosine-sampled bounce, none per mirror bounce (fused counts them apart)
+        assert 2 * st.paths + 2 * st.diffuse_bounces == int(want["draws"])
     if mode == 0:
         assert np.array_equal(rng, want["rng"])
     if engine == 0:

@@ -19,14 +19,17 @@ import scenes                          # noqa: E402
 from oracle import pt_oracle_py as po  # noqa: E402
 
 
-def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pass=16):
+def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pass=16, shading=0):
     V, T, M = scene
     with pt.PathTracer(w, h) as tr:
         tr.set_scene(*pt.make_scene(V, T, M))
         if engine == "wavefront":
-            tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT, depth=depth, samples_per_pass=samples_per_pass)
+            # strided RNG so that the wavefront engine batches samples; stride covers the worst case of either shading
+            tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT, depth=depth, samples_per_pass=samples_per_pass, shading=shading,
+                           rng_mode=pt.PT_RNG_STRIDED if shading else pt.PT_RNG_SEQUENTIAL, stride=2 + 2 * depth)
         else:
-            tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth)
+            tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth, shading=shading,
+                           rng_mode=pt.PT_RNG_STRIDED if shading else pt.PT_RNG_SEQUENTIAL, stride=2 + 2 * depth)
         tr.render(1)                    # warm-up (also restarts below)
         tr.set_options(depth=depth)     # restart accumulation
         t0 = time.perf_counter()
@@ -37,7 +40,8 @@ def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pa
     ok = None
     if check_pixels:
         ids = np.unique(np.random.default_rng(3).integers(0, w * h, check_pixels)).astype(np.uint32)
-        ref, _, _, _ = po.render(po.params(w, h, depth=depth, spp=spp), scene=po.make_scene(V, T, M), pixel_ids=ids)
+        ref, _, _, _ = po.render(po.params(w, h, depth=depth, spp=spp, shading=shading, stride=2 + 2 * depth,
+                                           rng_mode=po.RNG_STRIDED if shading else po.RNG_SEQUENTIAL), scene=po.make_scene(V, T, M), pixel_ids=ids)
         ok = bool(np.array_equal(img[ids].view(np.uint32), ref.view(np.uint32)))
     print(json.dumps({"config": name, "engine": engine, "triangles": len(T), "size": f"{w}x{h}", "spp": spp, "depth": depth,
                       "rays": int(st.rays), "rays_per_pixel_sample": round(st.rays / (w * h * spp), 3),
@@ -55,6 +59,9 @@ def main():
     if "c5" in which:
         for eng in ("fused", "wavefront"):
             run("C5 all materials depth 16", scenes.all_materials_scene(), 1920, 1080, args.spp, 16, eng)
+    if "c5x" in which:
+        for eng in ("fused", "wavefront"):
+            run("C5 mirror scene, EXTENDED shading, depth 16", scenes.mirror_scene(), 1920, 1080, args.spp, 16, eng, shading=1)
     if "c4small" in which:
         for n in (1000, 10000):
             sc = scenes.synthetic_scene(n)
