@@ -317,28 +317,35 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 	float delta_root = bv.kappa_root * s_ray + bv.slack;   // how far outside its triangle an accepted hit can be
 	float dt = 1.01f * delta_root / dlen;                  // ... in ray-parameter units
 	float tlo = -dt;
-	uint32_t cur = 0;
+	// Control flow is "while-while" (Aila & Laine): every lane first walks INNER nodes until it stands on a leaf (or is
+	// done) -- lanes that got there early wait --, then all lanes that hold a leaf test its triangles in lockstep, one
+	// triangle per trip.  Leaves are never tested inline in the node step: measured on the 10k-triangle scene, the
+	// inline form kept 8.5 of 64 lanes busy per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
+	constexpr int32_t kDone = 0x7FFFFFFF;
+	int32_t cur = 0;               // >= 0: inner node; < 0: leaf, ~cur = (first << 3) | (count - 1); kDone: finished
 	int sp = 0;
-	for (;;) {
-		const float4* n = bv.nodes + (size_t)cur * 4;
-		float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-		int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
-		float thi = best_t + dt + 1e-6f * best_t;
-		float tn0, tn1;
-		bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * s_ray + bv.slack, o, inv, tlo, thi, tn0);
-		bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * s_ray + bv.slack, o, inv, tlo, thi, tn1);
-		if (h0 && c0 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c0, bv.det_bounded, o, d, best_t, hit_tri); h0 = false; }
-		if (h1 && c1 < 0) { bvh_leaf(bv.leaves, (uint32_t)~c1, bv.det_bounded, o, d, best_t, hit_tri); h1 = false; }
-		if (h0 && h1) {
-			bool first0 = tn0 <= tn1;
-			if (sp < kBvhStackDepth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }
-			cur = (uint32_t)(first0 ? c0 : c1);
-		} else if (h0) cur = (uint32_t)c0;
-		else if (h1) cur = (uint32_t)c1;
-		else {
-			if (sp == 0) break;
-			sp--;
-			cur = stack[sp * 256];
+	while (cur != kDone) {
+		while ((uint32_t)cur < (uint32_t)kDone) {
+			const float4* n = bv.nodes + (size_t)cur * 4;
+			float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+			int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
+			float thi = best_t + dt + 1e-6f * best_t;
+			float tn0, tn1;
+			bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * s_ray + bv.slack, o, inv, tlo, thi, tn0);
+			bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * s_ray + bv.slack, o, inv, tlo, thi, tn1);
+			if (h0 && h1) {
+				bool first0 = tn0 <= tn1;
+				if (sp < kBvhStackDepth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }
+				cur = first0 ? c0 : c1;
+			} else if (h0) cur = c0;
+			else if (h1) cur = c1;
+			else if (sp == 0) cur = kDone;
+			else { sp--; cur = (int32_t)stack[sp * 256]; }
+		}
+		if (cur < 0) {
+			bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
+			if (sp == 0) cur = kDone;
+			else { sp--; cur = (int32_t)stack[sp * 256]; }
 		}
 	}
 }
