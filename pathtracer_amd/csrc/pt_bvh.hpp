@@ -31,7 +31,7 @@
 
 namespace ptbvh {
 
-constexpr uint32_t kLeafSize = 4;
+constexpr uint32_t kLeafSize = 4;                  // == ptd::kBvhLeafSize (pt_device.hpp: the traversal stack is sized from it)
 constexpr float kEps32 = 5.9604645e-8f;            // 2^-24
 constexpr float kKappaScale = 16.0f * kEps32 / 0.000001f;
 

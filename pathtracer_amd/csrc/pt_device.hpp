@@ -163,7 +163,15 @@ static_assert(sizeof(SceneHeader) == 64, "SceneHeader is 64 bytes");
 
 // Scenes above this many triangles carry a BVH and are traversed with it (pt_bvh.hpp).
 constexpr uint32_t kBvhMinTris = 512;    // measured crossover on MI355X: brute force wins at 432 triangles, the BVH 2-3x at 972
-constexpr int kBvhStackDepth = 24;                     // per-lane stack of deferred nodes, in LDS
+// Per-lane stack of deferred children, in LDS, [level][256 lanes].  The builder (pt_bvh.hpp) splits at the median down to
+// kBvhLeafSize triangles, so the tree is balanced and its inner depth -- the most the stack can ever hold, one deferred
+// sibling per level -- is known from the triangle count alone; 24 KiB for a fixed depth of 24 would cap a CU at 6 blocks.
+constexpr uint32_t kBvhLeafSize = 4;
+__host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
+	uint32_t d = 0;
+	while (n_tris > kBvhLeafSize) { n_tris = (n_tris + 1u) / 2u; d++; }    // the larger half decides
+	return d < 1u ? 1u : d;
+}
 
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
@@ -253,6 +261,7 @@ struct BvhView {
 	float kappa_root;        // largest kappa in the scene
 	float max_edge;          // longest triangle edge
 	bool det_bounded;        // SceneHeader::flags bit 0
+	int stack_depth;         // bvh_stack_depth(n_tris)
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -271,6 +280,7 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	v.kappa_root = hdr->kappa_root;
 	v.max_edge = hdr->max_edge;
 	v.det_bounded = (hdr->flags & kSceneDetBounded) != 0;
+	v.stack_depth = (int)bvh_stack_depth(n_tris);
 	return v;
 }
 
@@ -302,51 +312,79 @@ __device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint
 	}
 }
 
-// `stack` points at this lane's column of an LDS array laid out [level][256 lanes].
-__device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
-                                              uint32_t* stack) {
+// ---- traversal, in pieces so that a persistent kernel can refill idle lanes between the phases ----
+// Control flow is "while-while" (Aila & Laine): every lane first walks INNER nodes until it stands on a leaf (or is
+// done) -- lanes that got there early wait --, then all lanes that hold a leaf test its triangles in lockstep, one
+// triangle per trip.  Leaves are never tested inline in the node step: measured on the 10k-triangle scene, the
+// inline form kept 8.5 of 64 lanes busy per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
+constexpr int32_t kBvhDone = 0x7FFFFFFF;
+
+struct BvhRay {              // per-ray constants of the box tests
+	Vec3 inv;                // 1 / direction
+	float s_ray, dt, tlo;
+};
+
+__device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 d, float best_t) {
 	// a zero component would make 0 * inf = NaN in the slabs; a direction error of 1e-20 is far inside the inflation
 	Vec3 dd{ fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x, fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y,
 	         fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z };
-	Vec3 inv{ 1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z };
+	BvhRay r;
+	r.inv = Vec3{ 1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z };
 	float dlen = __builtin_sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
 	// S for THIS ray: an accepted hit has computed t < best_t, so its vertex is no farther from the origin
 	// than best_t*|d| + edge (+ the error delta itself, bounded with the launch-wide S); never more than s_bound
 	float delta_max = bv.kappa_root * bv.s_bound + bv.slack;
-	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
-	float delta_root = bv.kappa_root * s_ray + bv.slack;   // how far outside its triangle an accepted hit can be
-	float dt = 1.01f * delta_root / dlen;                  // ... in ray-parameter units
-	float tlo = -dt;
-	// Control flow is "while-while" (Aila & Laine): every lane first walks INNER nodes until it stands on a leaf (or is
-	// done) -- lanes that got there early wait --, then all lanes that hold a leaf test its triangles in lockstep, one
-	// triangle per trip.  Leaves are never tested inline in the node step: measured on the 10k-triangle scene, the
-	// inline form kept 8.5 of 64 lanes busy per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
-	constexpr int32_t kDone = 0x7FFFFFFF;
-	int32_t cur = 0;               // >= 0: inner node; < 0: leaf, ~cur = (first << 3) | (count - 1); kDone: finished
+	r.s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
+	float delta_root = bv.kappa_root * r.s_ray + bv.slack;   // how far outside its triangle an accepted hit can be
+	r.dt = 1.01f * delta_root / dlen;                        // ... in ray-parameter units
+	r.tlo = -r.dt;
+	return r;
+}
+
+// `stack` points at this lane's column of an LDS array laid out [level][256 lanes].
+// cur: >= 0 inner node; < 0 leaf, ~cur = (first << 3) | (count - 1); kBvhDone: finished.
+__device__ __forceinline__ int32_t bvh_pop(uint32_t* stack, int& sp) {
+	if (sp == 0) return kBvhDone;
+	sp--;
+	return (int32_t)stack[sp * 256];
+}
+
+// walks inner nodes until this lane stands on a leaf or is done
+__device__ __forceinline__ void bvh_node_phase(const BvhView& bv, const BvhRay& r, Vec3 o, float best_t, int32_t& cur, int& sp, uint32_t* stack) {
+	while ((uint32_t)cur < (uint32_t)kBvhDone) {
+		const float4* n = bv.nodes + (size_t)cur * 4;
+		float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+		int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
+		float thi = best_t + r.dt + 1e-6f * best_t;
+		float tn0, tn1;
+		bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn0);
+		bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn1);
+		if (h0 && h1) {
+			bool first0 = tn0 <= tn1;
+			if (sp < bv.stack_depth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }     // never false: see bvh_stack_depth
+			cur = first0 ? c0 : c1;
+		} else if (h0) cur = c0;
+		else if (h1) cur = c1;
+		else cur = bvh_pop(stack, sp);
+	}
+}
+
+// tests the leaf this lane stands on (if any) and pops
+__device__ __forceinline__ void bvh_leaf_phase(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri, int32_t& cur, int& sp, uint32_t* stack) {
+	if (cur < 0) {
+		bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
+		cur = bvh_pop(stack, sp);
+	}
+}
+
+__device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
+                                              uint32_t* stack) {
+	BvhRay r = bvh_ray_setup(bv, d, best_t);
+	int32_t cur = 0;
 	int sp = 0;
-	while (cur != kDone) {
-		while ((uint32_t)cur < (uint32_t)kDone) {
-			const float4* n = bv.nodes + (size_t)cur * 4;
-			float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-			int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
-			float thi = best_t + dt + 1e-6f * best_t;
-			float tn0, tn1;
-			bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * s_ray + bv.slack, o, inv, tlo, thi, tn0);
-			bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * s_ray + bv.slack, o, inv, tlo, thi, tn1);
-			if (h0 && h1) {
-				bool first0 = tn0 <= tn1;
-				if (sp < kBvhStackDepth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }
-				cur = first0 ? c0 : c1;
-			} else if (h0) cur = c0;
-			else if (h1) cur = c1;
-			else if (sp == 0) cur = kDone;
-			else { sp--; cur = (int32_t)stack[sp * 256]; }
-		}
-		if (cur < 0) {
-			bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
-			if (sp == 0) cur = kDone;
-			else { sp--; cur = (int32_t)stack[sp * 256]; }
-		}
+	while (cur != kBvhDone) {
+		bvh_node_phase(bv, r, o, best_t, cur, sp, stack);
+		bvh_leaf_phase(bv, o, d, best_t, hit_tri, cur, sp, stack);
 	}
 }
 

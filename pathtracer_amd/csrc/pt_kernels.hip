@@ -225,13 +225,62 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 	const uint32_t G = gridDim.x;
 	const uint32_t count = count_ptr[blockIdx.x];
 	const bool det_bounded = scene_det_bounded(scene);
-	__shared__ uint32_t s_stack[BVH ? kBvhStackDepth * kBlock : 1];
+	uint32_t* s_stack = reinterpret_cast<uint32_t*>(s_tris);      // BVH: the dynamic LDS is the traversal stack, bvh_stack_depth x 256 words
 	BvhView bv{};
 	if (BVH) bv = make_bvh_view(scene, n_tris, n_mats, camera);
 	const bool single = !BVH && n_tris <= kLdsTriChunk;
 	if (single) {
 		for (uint32_t k = threadIdx.x; k < n_tris * 4; k += kBlock) s_tris[k] = g_tris[k];
 		__syncthreads();
+	}
+	if (BVH) {
+		// Persistent traversal with lane refill: rays differ widely in how many nodes and leaves they visit, so a lane
+		// that has finished its ray takes the next one of this block's queue instead of idling until the slowest of its
+		// 64 neighbours is done (one LDS counter per block, one add per wave and refill; results are keyed by slot).
+		__shared__ uint32_t s_next;
+		if (threadIdx.x == 0) s_next = 0;
+		__syncthreads();
+		const uint32_t lane = threadIdx.x & 63u;
+		uint32_t* stack = s_stack + threadIdx.x;
+		uint32_t q = 0, tri = kNoHit;
+		float best = 0.0f;
+		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
+		BvhRay r{};
+		int32_t cur = kBvhDone;
+		int sp = 0;
+		bool has_ray = false, exhausted = false;
+		for (;;) {
+			bool idle = cur == kBvhDone;
+			if (idle && has_ray) { hit[q] = uint2{ __float_as_uint(best), tri }; has_ray = false; }
+			unsigned long long idle_mask = __ballot(idle);
+			uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+			// refill when a quarter of the wave idles (the set-up of a ray costs about as much as two node steps)
+			if (!exhausted && (n_idle >= 16u || n_idle == 64u)) {
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(&s_next, n_idle);
+				base = __shfl(base, 0, 64);
+				uint32_t j = base + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+				if (base + n_idle >= count) exhausted = true;          // wave-uniform: nothing left after this hand-out
+				if (idle && j < count) {
+					q = ((j / kBlock) * G + blockIdx.x) * kBlock + (j % kBlock);
+					if (q < capacity) {
+						float4 a = float4{ 0, 0, 0, 0 };
+						if (!FIRST) a = qa[q];
+						float4 b = qb[q];
+						o = FIRST ? Vec3{ origin.x, origin.y, origin.z } : Vec3{ a.x, a.y, a.z };
+						d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
+						best = FIRST ? FLT_MAX : b.z;
+						tri = kNoHit;
+						r = bvh_ray_setup(bv, d, best);
+						cur = 0; sp = 0; has_ray = true;
+					}
+				}
+			}
+			if (!__any(cur != kBvhDone)) { if (exhausted) break; else continue; }
+			bvh_node_phase(bv, r, o, best, cur, sp, stack);
+			bvh_leaf_phase(bv, o, d, best, tri, cur, sp, stack);
+		}
+		return;
 	}
 	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
 		uint32_t q = queue_slot(j0, G) + threadIdx.x;
@@ -242,9 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 		Vec3 d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
 		float best = FIRST ? FLT_MAX : b.z;
 		uint32_t tri = kNoHit;
-		if (BVH) {
-			if (active) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
-		} else if (single) {
+		if (single) {
 			if (active) intersect_range(s_tris, 0, n_tris, det_bounded, o, d, best, tri);
 		} else {
 			for (uint32_t c0 = 0; c0 < n_tris; c0 += kLdsTriChunk) {
@@ -433,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 	constexpr bool BVH = SCENE == 2;
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
-	__shared__ uint32_t s_stack[BVH ? kBvhStackDepth * kBlock : 1];
+	uint32_t* s_stack = reinterpret_cast<uint32_t*>(s_scene);     // BVH: the dynamic LDS is the traversal stack, bvh_stack_depth x 256 words
 	// STRIDED: the two jump matrices are read from LDS, not kept in 64 SGPRs across the pixel loop (106 SGPRs admit
 	// 6 blocks per CU, 74 admit 8)
 	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1];
@@ -583,7 +630,7 @@ void launch_extend(const FrameDev& f, uint32_t bounce, const void* scene_blob, c
 	dim3 grid(grid_for(capacity)), block(kBlock);
 	const unsigned char* sc = (const unsigned char*)scene_blob;
 	bool bvh = scene_has_bvh(si);
-	size_t lds = bvh ? 0 : extend_lds_bytes(si.n_tris);
+	size_t lds = bvh ? (size_t)bvh_stack_depth(si.n_tris) * kBlock * sizeof(uint32_t) : extend_lds_bytes(si.n_tris);
 #define PT_EXT(FIRST, BVH) hipLaunchKernelGGL((k_extend<FIRST, BVH>), grid, block, lds, s, f.origin, f.origin, sc, si.n_tris, si.n_mats, qa, qb, counts, capacity, hit)
 	if (bounce == 0) { if (bvh) PT_EXT(true, true); else PT_EXT(true, false); }
 	else { if (bvh) PT_EXT(false, true); else PT_EXT(false, false); }
@@ -935,7 +982,8 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	// runs at 2.4 cycles/instruction, an SGPR operand halves that -- tools/valu_microbench.hip), through the scalar
 	// cache when it does not, above kBvhMinTris the BVH.  Measured on the default scene: LDS 208, scalar 202 Grays/s.
 	int mode = scene_has_bvh(si) ? 2 : shade_scene_in_lds(si) ? 1 : 0;
-	size_t lds_bytes = (mode == 1 ? shade_lds_bytes(si) : 0) + (mode != 2 && si.n_tris <= kPrimMaxTris ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
+	size_t lds_bytes = (mode == 1 ? shade_lds_bytes(si) : 0) + (mode != 2 && si.n_tris <= kPrimMaxTris ? (size_t)si.n_tris * sizeof(PrimRec) : 0) +
+	                   (mode == 2 ? (size_t)bvh_stack_depth(si.n_tris) * kBlock * sizeof(uint32_t) : 0);
 	// One lane per pixel, every block its own 256 pixels: measured on MI355X (1080p, 64 spp) the
 	// hardware scheduler back-filling 8100 short-lived blocks beats any persistent grid-stride
 	// grid (145 vs 131 Grays/s at 8 blocks/CU) because the kernel holds 77 VGPRs = 6 waves/SIMD and a
