@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import pathtracer_amd as pt, scenes
 lib = pt.load_library()
 for n in (48, 100, 200, 400, 1000, 3000):
@@ -17,4 +17,4 @@ for n in (48, 100, 200, 400, 1000, 3000):
                 st = tr.stats()
                 row.append(round(st.rays / st.total_render_ms / 1e3, 1))
     print(len(sc[1]), "tris  Mrays/s  brute fused/wave:", row[0], row[1], " bvh fused/wave:", row[2], row[3], flush=True)
-lib.pt_hip_set_bvh_threshold(64)
+lib.pt_hip_set_bvh_threshold(512)

@@ -59,6 +59,32 @@ def main():
     if "c5" in which:
         for eng in ("fused", "wavefront"):
             run("C5 all materials depth 16", scenes.all_materials_scene(), 1920, 1080, args.spp, 16, eng)
+    if "c3" in which:
+        # BASELINE configs[2], one rank's share: 3840x2160, samples [3*128, 4*128) of the 1024-sample frame (rank 3 of 8),
+        # strided RNG stride 35 = the reference's own stream on this scene
+        w, h, spp, rank = 3840, 2160, 128, 3
+        for eng in ("fused", "wavefront"):
+            with pt.PathTracer(w, h) as tr:
+                tr.set_options(engine=pt.PT_ENGINE_FUSED if eng == "fused" else pt.PT_ENGINE_WAVEFRONT, rng_mode=pt.PT_RNG_STRIDED, stride=35,
+                               samples_per_pass=8, sample_offset=rank * spp)
+                tr.render(1)
+                tr.set_options(sample_offset=rank * spp)
+                t0 = time.perf_counter()
+                tr.render(spp)
+                dt = time.perf_counter() - t0
+                st = tr.stats()
+                img = tr.readback()
+            ids = np.unique(np.random.default_rng(5).integers(0, w * h, 1500)).astype(np.uint32)
+            # the oracle renders the same 128 samples: RNG index frame_first = rank*spp, mean index from 0
+            ref = np.ones((len(ids), 4), dtype=np.float32)
+            for s_ in range(spp):
+                _, _, _, frame = po.render(po.params(w, h, spp=1, rng_mode=po.RNG_STRIDED, stride=35, frame_first=rank * spp + s_), pixel_ids=ids, want_last_frame=True)
+                r = np.float32(1.0) / np.float32(s_ + 1)
+                ref = (frame * r + (ref * np.float32(s_)) * r).astype(np.float32)
+            ok = bool(np.array_equal(img[ids].view(np.uint32), ref.view(np.uint32)))
+            print(json.dumps({"config": "C3 share of rank 3/8: 3840x2160, 128 of 1024 spp", "engine": eng, "rays": int(st.rays), "device_ms": round(st.total_render_ms, 3),
+                              "wall_ms": round(dt * 1e3, 3), "Mrays_per_s": round(st.rays / (st.total_render_ms * 1e-3) / 1e6, 1),
+                              "oracle_bit_exact_on_sampled_pixels": ok}), flush=True)
     if "c5x" in which:
         for eng in ("fused", "wavefront"):
             run("C5 mirror scene, EXTENDED shading, depth 16", scenes.mirror_scene(), 1920, 1080, args.spp, 16, eng, shading=1)
