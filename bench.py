@@ -64,6 +64,21 @@ def cpu_baseline(spp):
             "sample": f"default scene {WIDTH}x{HEIGHT}, {spp} spp, depth {DEPTH}: {st.rays} rays in {dt:.2f} s wall"}
 
 
+def parity_sample(tracer, w, h, spp_total, n_pixels=2048):
+    """BASELINE.json's third metric, 'RMSE vs reference': a bounded sample of pixels of the image the timed steps
+    produced, against the oracle rendering the same pixels and samples (sequential RNG = the reference's stream)."""
+    from oracle import pt_oracle_py as po
+    img = tracer.readback()
+    ids = np.unique(np.random.default_rng(7).integers(0, w * h, n_pixels)).astype(np.uint32)
+    ref, _, _, _ = po.render(po.params(w, h, depth=DEPTH, spp=spp_total), pixel_ids=ids)
+    got = img[ids]
+    equal = int((got.view(np.uint32) == ref.view(np.uint32)).all(axis=1).sum())
+    diff = got.astype(np.float64) - ref.astype(np.float64)
+    rel = np.abs(diff) / np.maximum(np.abs(ref.astype(np.float64)), 1e-6)
+    return {"pixels_checked": int(len(ids)), "pixels_bit_identical": equal, "rmse": float(np.sqrt((diff ** 2).mean())),
+            "max_rel_err": float(rel.max()), "spp": int(spp_total), "against": "oracle (CPU restatement of the reference path), same pixels and samples"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +244,8 @@ def main():
             ginst = valu_insts / (last_ms * 1e-3) / 1e9
             out["roofline_valu"] = {"bound": "valu", "achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave64-instructions/s",
                                     "frac": round(ginst / VALU_PEAK_GINST, 4), "instructions_per_launch": valu_insts}
+        if world == 1 and not dist and args.engine == "fused" and args.cpu_spp > 0:
+            out["parity"] = parity_sample(tracer, w, h, total_steps * SPP_PER_STEP)
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp)
         else:
