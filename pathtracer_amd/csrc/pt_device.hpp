@@ -318,6 +318,10 @@ __device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint
 // triangle per trip.  Leaves are never tested inline in the node step: measured on the 10k-triangle scene, the
 // inline form kept 8.5 of 64 lanes busy per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
 constexpr int32_t kBvhDone = 0x7FFFFFFF;
+#ifndef PT_BVH_SPECULATE
+#define PT_BVH_SPECULATE 0     // measured: parking one leaf and walking on costs 25-30 % (10k triangles 2.77 -> 2.02 Grays/s): the parked leaf usually ends the search
+#endif
+constexpr bool kBvhSpeculate = PT_BVH_SPECULATE != 0;
 
 struct BvhRay {              // per-ray constants of the box tests
 	Vec3 inv;                // 1 / direction
@@ -349,28 +353,37 @@ __device__ __forceinline__ int32_t bvh_pop(uint32_t* stack, int& sp) {
 	return (int32_t)stack[sp * 256];
 }
 
-// walks inner nodes until this lane stands on a leaf or is done
-__device__ __forceinline__ void bvh_node_phase(const BvhView& bv, const BvhRay& r, Vec3 o, float best_t, int32_t& cur, int& sp, uint32_t* stack) {
-	while ((uint32_t)cur < (uint32_t)kBvhDone) {
-		const float4* n = bv.nodes + (size_t)cur * 4;
-		float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-		int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
-		float thi = best_t + r.dt + 1e-6f * best_t;
-		float tn0, tn1;
-		bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn0);
-		bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn1);
-		if (h0 && h1) {
-			bool first0 = tn0 <= tn1;
-			if (sp < bv.stack_depth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }     // never false: see bvh_stack_depth
-			cur = first0 ? c0 : c1;
-		} else if (h0) cur = c0;
-		else if (h1) cur = c1;
-		else cur = bvh_pop(stack, sp);
+// One round of the traversal: walk inner nodes until the lane stands on a leaf (or is done), then test that leaf's
+// triangles, every lane in lockstep.  With PT_BVH_SPECULATE a lane that reaches a leaf parks it in `pend` and keeps
+// walking until it holds a second leaf, so that fewer lanes idle while the slowest lane still looks for its first
+// one -- tried, and slower (see the define).  The order in which leaves are tested cannot
+// change the result: bvh_leaf ranks hits by (t, original index).
+__device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
+                                          int32_t& cur, int& sp, uint32_t* stack) {
+	constexpr int32_t kNone = 0;                       // node 0 is the root and never a child, so 0 is free as "no parked leaf"
+	int32_t pend = kNone;
+	for (;;) {
+		if ((uint32_t)cur < (uint32_t)kBvhDone) {
+			const float4* n = bv.nodes + (size_t)cur * 4;
+			float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+			int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
+			float thi = best_t + r.dt + 1e-6f * best_t;
+			float tn0, tn1;
+			bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn0);
+			bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn1);
+			if (h0 && h1) {
+				bool first0 = tn0 <= tn1;
+				if (sp < bv.stack_depth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }     // never false: see bvh_stack_depth
+				cur = first0 ? c0 : c1;
+			} else if (h0) cur = c0;
+			else if (h1) cur = c1;
+			else cur = bvh_pop(stack, sp);
+		} else if (kBvhSpeculate && cur < 0 && pend == kNone) {
+			pend = cur;
+			cur = bvh_pop(stack, sp);
+		} else break;
 	}
-}
-
-// tests the leaf this lane stands on (if any) and pops
-__device__ __forceinline__ void bvh_leaf_phase(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri, int32_t& cur, int& sp, uint32_t* stack) {
+	if (pend != kNone) bvh_leaf(bv.leaves, (uint32_t)~pend, bv.det_bounded, o, d, best_t, hit_tri);
 	if (cur < 0) {
 		bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
 		cur = bvh_pop(stack, sp);
@@ -382,10 +395,7 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 	BvhRay r = bvh_ray_setup(bv, d, best_t);
 	int32_t cur = 0;
 	int sp = 0;
-	while (cur != kBvhDone) {
-		bvh_node_phase(bv, r, o, best_t, cur, sp, stack);
-		bvh_leaf_phase(bv, o, d, best_t, hit_tri, cur, sp, stack);
-	}
+	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack);
 }
 
 // GetDiffuseReflection, Functions.cuh:91-109: rounds of 3 draws (x, y, z in that order) until

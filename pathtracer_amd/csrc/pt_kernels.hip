@@ -277,8 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 				}
 			}
 			if (!__any(cur != kBvhDone)) { if (exhausted) break; else continue; }
-			bvh_node_phase(bv, r, o, best, cur, sp, stack);
-			bvh_leaf_phase(bv, o, d, best, tri, cur, sp, stack);
+			bvh_round(bv, r, o, d, best, tri, cur, sp, stack);
 		}
 		return;
 	}
