@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <float.h>
 
+#include "pt_hip.h"      // PT_MAT_*, PT_SHADING_*
+
 #pragma clang fp contract(off)
 
 namespace ptd {

@@ -70,11 +70,11 @@ static Report run(K kernel) {
 	Report h{};
 	h.min_abs_bits = 0xFFFFFFFFu;
 	if (hipMalloc(&d, sizeof(Report)) != hipSuccess) { std::printf("hipMalloc failed\n"); std::exit(2); }
-	hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice);
+	(void)hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice);
 	hipLaunchKernelGGL(kernel, dim3(256 * 16), dim3(256), 0, 0, d);
 	if (hipDeviceSynchronize() != hipSuccess) { std::printf("kernel failed\n"); std::exit(2); }
-	hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
-	hipFree(d);
+	(void)hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
 	return h;
 }
 
