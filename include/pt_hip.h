@@ -56,6 +56,12 @@ enum { PT_RNG_SEQUENTIAL = 0, PT_RNG_STRIDED = 1 };
  * throughput reflectivity*color, DIFFUSE samples the cosine-weighted hemisphere (2 draws, throughput = color). */
 enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
 
+/* pt_frame.flags.  PT_FRAME_FAST_DIV: the kernels may replace the two IEEE divisions of InitializeRays, (x + u) / width and
+ * (y + u) / height (kernels.cu:39-40), by a multiply and two fused residual corrections with the correctly rounded
+ * reciprocal (5 VALU instructions for 11).  Set it ONLY after pt_hip_verify_fast_div has confirmed, for this width and
+ * this height, that the short form returns the IEEE quotient for EVERY float32 numerator that can occur. */
+#define PT_FRAME_FAST_DIV 1u
+
 /* Which kernels execute a render call. */
 enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1 };
 
@@ -74,7 +80,8 @@ typedef struct {
     uint32_t  rng_mode;
     uint32_t  stride;                    /* STRIDED only */
     uint32_t  shading;                   /* PT_SHADING_REFERENCE (default) or PT_SHADING_EXTENDED */
-    uint32_t  _reserved[3];              /* zero */
+    uint32_t  flags;                     /* PT_FRAME_* */
+    uint32_t  _reserved[2];              /* zero */
     pt_float4 origin, top_left, bottom_left, bottom_right;  /* Camera.h:49-77 */
 } pt_frame;
 
@@ -120,6 +127,11 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
                       const pt_triangle* triangles, uint32_t n_triangles,
                       const pt_material* materials, uint32_t n_materials,
                       void* host_blob, size_t blob_bytes);
+
+/* Exhaustive check on the device (a few ms, cached per denominator): *ok = 1 iff for every float32 a in [2^-32, denominator + 1]
+ * (the numerators pixel + u that can occur)
+ * the short division of PT_FRAME_FAST_DIV equals a / (float)denominator bit for bit.  Synchronises `stream`. */
+int pt_hip_verify_fast_div(uint32_t denominator, int* ok, void* stream);
 
 /* ---- a1: InitializeRng (kernels.cu:25-30) + RngInit (Functions.cuh:31-38).
  * rng[k] = step^((pixel_first+k)/32)(seed + pixel_first + k), by O(log) GF(2) jump-ahead

@@ -24,6 +24,7 @@ PT_RNG_SEQUENTIAL, PT_RNG_STRIDED = 0, 1
 PT_ENGINE_WAVEFRONT, PT_ENGINE_FUSED = 0, 1
 PT_MAT_DIFFUSE, PT_MAT_REFLECTIVE, PT_MAT_EMISSIVE = 0, 1, 2
 PT_SHADING_REFERENCE, PT_SHADING_EXTENDED = 0, 1
+PT_FRAME_FAST_DIV = 1
 PT_MAX_DEPTH = 32
 PT_STATS_WORDS = 4 + PT_MAX_DEPTH
 
@@ -62,7 +63,7 @@ class CameraData(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
                 ("depth", C.c_uint32), ("seed", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32),
-                ("shading", C.c_uint32), ("_reserved", C.c_uint32 * 3),
+                ("shading", C.c_uint32), ("flags", C.c_uint32), ("_reserved", C.c_uint32 * 2),
                 ("origin", Float4), ("top_left", Float4), ("bottom_left", Float4), ("bottom_right", Float4)]
 
 
@@ -136,6 +137,7 @@ SYMBOLS = {
     "pt_hip_set_bvh_threshold": (C.c_int, [_U32]),
     "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),
     "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
+    "pt_hip_verify_fast_div": (C.c_int, [_U32, C.POINTER(C.c_int), _VP]),
     "pt_hip_rng_seed": (C.c_int, [_FRAMEP, _VP, _VP]),
     "pt_hip_queue_blocks": (_U32, [_U32]),
     "pt_hip_generate": (C.c_int, [_FRAMEP, _U32, _U32, _VP, _VP, _VP, _U32, Queue, _VP, _U32, _VP, _VP]),

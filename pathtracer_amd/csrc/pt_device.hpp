@@ -133,7 +133,11 @@ __device__ __forceinline__ float sqrt_ieee(float x) {
 }
 
 // helper_math.h:62-65 host form of rsqrtf = 1.0f / sqrtf(x): two correctly rounded operations.
-__device__ __forceinline__ float rsqrt_ref(float x) { return rcp_ieee(sqrt_ieee(x)); }
+// (one range check: for 2^-100 <= x <= 1e30 the root is in [2^-50, 1e15], inside the reciprocal's range)
+__device__ __forceinline__ float rsqrt_ref(float x) {
+	if (__builtin_expect(x >= kSqrtLo && x <= 1.0e30f, 1)) return rcp_newton(sqrt_fixup(x));
+	return 1.0f / __builtin_sqrtf(x);
+}
 // the same for 2^-100 <= x < 2^128: sqrt is then in [2^-50, 2^64)
 __device__ __forceinline__ float rsqrt_ref_bounded(float x) { return rcp_newton(sqrt_fixup(x)); }
 
@@ -493,12 +497,26 @@ struct FrameDev {
 	uint32_t pixel_first, pixel_count;
 	uint32_t depth, seed, rng_mode, stride;
 	uint32_t shading;
+	uint32_t fast_div;             // PT_FRAME_FAST_DIV: rcp_width / rcp_height may be used (verified per size)
+	float    rcp_width, rcp_height; // correctly rounded 1 / width, 1 / height
 	float4   origin, top_left, bottom_left, bottom_right;
 };
 
+// a / b with rb = RN(1 / b): q0 = a * rb, then two residual corrections q += fma(-q, b, a) * rb (Markstein: with a correctly
+// rounded reciprocal and a faithful q the corrected quotient is the correctly rounded one; the first correction makes q
+// faithful).  Used only under PT_FRAME_FAST_DIV, i.e. after pt_hip_verify_fast_div has compared it with the IEEE division
+// for every numerator that can occur with this b.
+__device__ __forceinline__ float div_by(float a, float b, float rb) {
+	float q = a * rb;
+	q = __builtin_fmaf(__builtin_fmaf(-q, b, a), rb, q);
+	return __builtin_fmaf(__builtin_fmaf(-q, b, a), rb, q);
+}
+
 __device__ __forceinline__ Vec3 primary_direction(const FrameDev& f, uint32_t px, uint32_t py, uint32_t& rng) {
-	float xs = ((float)px + rng_uniform(rng)) / (float)f.width;    // :39
-	float ys = ((float)py + rng_uniform(rng)) / (float)f.height;   // :40
+	float ax = (float)px + rng_uniform(rng), xs;                   // :39  (x + u) / width
+	float ay = (float)py + rng_uniform(rng), ys;                   // :40  (y + u) / height
+	if (f.fast_div) { xs = div_by(ax, (float)f.width, f.rcp_width); ys = div_by(ay, (float)f.height, f.rcp_height); }
+	else { xs = ax / (float)f.width; ys = ay / (float)f.height; }
 	float4 bl = f.bottom_left, br = f.bottom_right, tl = f.top_left;
 	float px4 = (bl.x + (br.x - bl.x) * xs) + (tl.x - bl.x) * ys;  // :44
 	float py4 = (bl.y + (br.y - bl.y) * xs) + (tl.y - bl.y) * ys;

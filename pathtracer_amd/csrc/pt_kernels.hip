@@ -76,6 +76,8 @@ FrameDev to_dev(const pt_frame& f) {
 	d.width = f.width; d.height = f.height;
 	d.pixel_first = f.pixel_first; d.pixel_count = f.pixel_count;
 	d.depth = f.depth; d.seed = f.seed; d.rng_mode = f.rng_mode; d.stride = f.stride; d.shading = f.shading;
+	d.fast_div = (f.flags & PT_FRAME_FAST_DIV) ? 1u : 0u;
+	d.rcp_width = 1.0f / (float)f.width; d.rcp_height = 1.0f / (float)f.height;      // host IEEE division: correctly rounded
 	d.origin = float4{ f.origin.x, f.origin.y, f.origin.z, f.origin.w };
 	d.top_left = float4{ f.top_left.x, f.top_left.y, f.top_left.z, f.top_left.w };
 	d.bottom_left = float4{ f.bottom_left.x, f.bottom_left.y, f.bottom_left.z, f.bottom_left.w };
@@ -461,6 +463,17 @@ __global__ __launch_bounds__(kBlock) void k_fold_counts(const uint32_t* __restri
 	}
 }
 
+// pt_hip_verify_fast_div: every float32 a in [2^-32, denominator + 1], as bit patterns first .. last (the numerator is
+// pixel + u with u = (float)x * 2^-32 >= 2^-32; tiny numerators, whose quotients go denormal, are where the short form fails)
+__global__ __launch_bounds__(kBlock) void k_verify_div(float b, float rb, uint32_t first, uint32_t last, uint32_t* __restrict__ mismatches) {
+	uint32_t bad = 0;
+	for (unsigned long long k = (unsigned long long)first + (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k <= last; k += (unsigned long long)gridDim.x * kBlock) {
+		float a = __uint_as_float((uint32_t)k);
+		bad += __float_as_uint(a / b) != __float_as_uint(div_by(a, b, rb));
+	}
+	if (bad) atomicAdd(mismatches, bad);
+}
+
 __global__ __launch_bounds__(kBlock) void k_fill_f32(float* __restrict__ dst, float value, size_t n) {
 	for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (size_t)gridDim.x * kBlock) dst[k] = value;
 }
@@ -816,6 +829,37 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 		r[2] = r[3] = 0.0f;
 		r[4] = materials[k].color.x; r[5] = materials[k].color.y; r[6] = materials[k].color.z; r[7] = materials[k].color.w;
 	}
+	return PT_OK;
+}
+
+int pt_hip_verify_fast_div(uint32_t denominator, int* ok, void* stream) {
+	if (!ok) return fail(PT_ERR_INVALID, "verify_fast_div: ok is null");
+	*ok = 0;
+	if (denominator == 0 || denominator > (1u << 24)) return PT_OK;          // beyond 2^24 the float is not the integer: keep the IEEE division
+	static std::mutex mu;
+	static std::vector<std::pair<uint32_t, int>> cache;
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		for (auto& e : cache) if (e.first == denominator) { *ok = e.second; return PT_OK; }
+	}
+	hipStream_t s = (hipStream_t)stream;
+	uint32_t* d_bad = nullptr;
+	HIP_TRY(hipMalloc(&d_bad, sizeof(uint32_t)));
+	float b = (float)denominator, top = b + 1.0f;
+	uint32_t last; std::memcpy(&last, &top, 4);
+	hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_verify_div, dim3(grid_for((size_t)1 << 24)), dim3(kBlock), 0, s, b, 1.0f / b, 0x2F800000u, last, d_bad);
+		e = hipGetLastError();
+	}
+	uint32_t bad = 1;
+	if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	(void)hipFree(d_bad);
+	if (e != hipSuccess) return hip_fail(e, "verify_fast_div");
+	*ok = bad == 0 ? 1 : 0;
+	std::lock_guard<std::mutex> lock(mu);
+	cache.emplace_back(denominator, *ok);
 	return PT_OK;
 }
 

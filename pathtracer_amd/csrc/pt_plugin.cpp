@@ -78,6 +78,7 @@ class PathTracer final : public IPathTracer {
 	void* _evStop = nullptr;
 	double _lastMs = 0.0, _totalMs = 0.0;
 	uint64_t _renders = 0;
+	uint32_t _frameFlags = 0;           // PT_FRAME_FAST_DIV once both image sizes are verified
 	int _error = PT_OK;                 // sticky: once a device call fails the object stops rendering
 
 public:
@@ -279,6 +280,7 @@ private:
 		f.pixel_first = _pixelFirst; f.pixel_count = _pixelCount;
 		f.depth = _opt.depth; f.seed = _opt.seed; f.rng_mode = _opt.rng_mode; f.stride = _opt.stride;
 		f.shading = _opt.shading;
+		f.flags = _frameFlags;
 		f.origin = _camera.GetPosition();
 		f.top_left = _camera.GetTopLeft();
 		f.bottom_left = _camera.GetBottomLeft();
@@ -294,6 +296,11 @@ private:
 		_pixelCount = _opt.pixel_count ? _opt.pixel_count : (uint32_t)(n - _pixelFirst);
 		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace);
 		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _workspaceBytes = 0;
+		// the short division of the ray set-up is used only for sizes it is verified for (exhaustively, on the device)
+		int okW = 0, okH = 0;
+		PT_TRY(pt_hip_verify_fast_div((uint32_t)_width, &okW, _stream));
+		PT_TRY(pt_hip_verify_fast_div((uint32_t)_height, &okH, _stream));
+		_frameFlags = (okW && okH) ? PT_FRAME_FAST_DIV : 0u;
 		PT_TRY(pt_hip_malloc((void**)&_dev.rng, (size_t)_pixelCount * sizeof(uint32_t)));
 		PT_TRY(pt_hip_malloc(&_dev.mean, (size_t)_pixelCount * 4 * sizeof(float)));
 		// the reference's surface starts white (Surface.cpp:99-115); frame 0 multiplies it by 0
