@@ -312,7 +312,10 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 // rng word when the streams are written back), an emitter hit adds the throughput, only a diffuse
 // hit reads the ray.  EXTEND (scene in LDS): the new ray is intersected at once (a5+a6 fused into
 // the producer) and the hit stored with the continuing path, so no extend pass re-reads it.
-template <bool FIRST, bool SCENE_LDS, bool EXTEND>
+// GEN (bounce 0 of an LDS-resident scene): the bounce-0 queue is never materialised -- the camera ray of slot q is
+// generated and intersected right here (a4 fused into its consumer), which takes generate's 24 B per path of writes
+// and this kernel's reads of them off the bus.
+template <bool FIRST, bool SCENE_LDS, bool EXTEND, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
                                                   const float4* __restrict__ qa, const float4* __restrict__ qb,
@@ -324,8 +327,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
                                                   uint2* __restrict__ ohit,
                                                   uint32_t* __restrict__ count_out,
                                                   float4* __restrict__ radiance, unsigned char* __restrict__ lit,
-                                                  uint32_t* __restrict__ rng_out) {
+                                                  uint32_t* __restrict__ rng_out,
+                                                  const uint32_t* __restrict__ smat, const uint32_t* __restrict__ rng_in) {
 	static_assert(!EXTEND || SCENE_LDS, "the fused extend intersects against the LDS copy of the scene");
+	static_assert(!GEN || (FIRST && EXTEND), "generation is fused into the first shade of an LDS-resident scene only");
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
 	stage_jump31(s_jump);
@@ -339,7 +344,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 		for (uint32_t k = threadIdx.x; k < nt4; k += kBlock) s_scene[k] = g_tris[k];
 		for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = g_mats[k];
 		tris = s_scene; mats = s_scene + nt4;
+		if (GEN) stage_primary_records(g_tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_scene + nt4 + nm2);
 	}
+	const float4* s_prim = s_scene + n_tris * 4 + n_mats * 2;
 	const uint32_t G = gridDim.x;
 	const uint32_t count = count_ptr[blockIdx.x];
 	const uint32_t lane = threadIdx.x & 63u;
@@ -356,8 +363,31 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
 		float t = 0.0f;
 		uint32_t rng = 0, pid = q, next_tri = kNoHit;
+		// GEN: which sample of the pass this slot belongs to decides the jump matrix; almost always one sample per wave
+		uint32_t gen_s = 0, gen_li = 0;
+		bool gen_uniform = true;
+		if (GEN) {
+			gen_s = active ? q / f.pixel_count : 0u;
+			gen_li = q - gen_s * f.pixel_count;
+			uint32_t s_first = __builtin_amdgcn_readfirstlane(active ? gen_s : 0xFFFFFFFFu);
+			gen_uniform = __ballot(active && gen_s != s_first) == 0ull;
+			if (gen_uniform && s_first != 0xFFFFFFFFu) gen_s = s_first;
+		}
 		if (active) {
-			uint2 h = hit[q];
+			uint2 h;
+			float4 gen_b = float4{ 0, 0, 0, 0 };
+			if (GEN) {
+				uint32_t i = f.pixel_first + gen_li;
+				uint32_t r0 = rng_in[gen_li];
+				if (f.rng_mode == PT_RNG_STRIDED) r0 = gen_uniform ? mat_apply(smat + 32u * __builtin_amdgcn_readfirstlane(gen_s), r0) : mat_apply(smat + 32u * gen_s, r0);
+				uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
+				Vec3 gd = primary_direction(f, px, py, r0);
+				float best = FLT_MAX;
+				uint32_t ptri = kNoHit;
+				intersect_range_primary(tris, s_prim, n_tris, det_bounded, gd, best, ptri);
+				h = uint2{ __float_as_uint(best), ptri };
+				gen_b = float4{ gd.x, gd.y, gd.z, __uint_as_float(r0) };
+			} else h = hit[q];
 			if (!FIRST) pid = qpid[q];
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
 			uint32_t type = 0xFFFFFFFFu;
@@ -376,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 			bool emitted = false;
 			// REFERENCE: only DIFFUSE continues (kernels.cu:79-93); EXTENDED: every hit that is not an emitter does
 			if (type == PT_MAT_DIFFUSE || (extended && h.y != kNoHit && type != PT_MAT_EMISSIVE)) {
-				float4 b = qb[q];
+				float4 b = GEN ? gen_b : qb[q];
 				if (FIRST) {
 					o = Vec3{ f.origin.x, f.origin.y, f.origin.z }; d = Vec3{ b.x, b.y, b.z };
 				} else {
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 					emitted = true;
 				}
 				// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
-				if (rng_out) rng = __float_as_uint(qb[q].w);
+				if (rng_out) rng = __float_as_uint(GEN ? gen_b.w : qb[q].w);
 			}
 			if (!cont || last_bounce) {
 				// every path that ends sets its flag; only emitter hits carry a radiance, all others are (0,0,0,1)
@@ -907,20 +937,24 @@ int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob
 	return PT_OK;
 }
 
+// gen_rng != nullptr: bounce 0 generates its camera rays itself (k_shade<..., GEN>); gen_smat = the pass's jump matrices (STRIDED)
 static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneInfo& si, uint32_t bounce,
                         pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
-                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s) {
+                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s,
+                        const uint32_t* gen_smat = nullptr, const uint32_t* gen_rng = nullptr) {
 	uint32_t last = (bounce + 1 >= f.depth) ? 1u : 0u;
 	bool lds = shade_scene_in_lds(si);
 	bool extend = hit_out != nullptr;
 	if (extend && !lds) return fail(PT_ERR_INVALID, "shade: the fused extend needs a scene that fits LDS (<= 1536 triangles, <= 256 materials)");
-	size_t lds_bytes = shade_lds_bytes(si);
+	bool gen = gen_rng != nullptr;
+	if (gen && !(bounce == 0 && extend)) return fail(PT_ERR_INVALID, "shade: generation can only be fused into bounce 0 of an LDS-resident scene");
+	size_t lds_bytes = shade_lds_bytes(si) + (gen ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
 	dim3 grid(grid_for(capacity)), block(kBlock);
-#define PT_SHADE(FIRST, LDS, EXT) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
+#define PT_SHADE(FIRST, LDS, EXT, GEN) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT, GEN>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
 	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
-	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng)
-	if (bounce == 0) { if (extend) PT_SHADE(true, true, true); else if (lds) PT_SHADE(true, true, false); else PT_SHADE(true, false, false); }
-	else { if (extend) PT_SHADE(false, true, true); else if (lds) PT_SHADE(false, true, false); else PT_SHADE(false, false, false); }
+	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng, gen_smat, gen_rng)
+	if (bounce == 0) { if (gen) PT_SHADE(true, true, true, true); else if (extend) PT_SHADE(true, true, true, false); else if (lds) PT_SHADE(true, true, false, false); else PT_SHADE(true, false, false, false); }
+	else { if (extend) PT_SHADE(false, true, true, false); else if (lds) PT_SHADE(false, true, false, false); else PT_SHADE(false, false, false, false); }
 #undef PT_SHADE
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
@@ -987,8 +1021,10 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 		uint32_t ns = std::min(samples_per_pass, n_samples - done);
 		uint32_t paths = ns * frame->pixel_count;
 		hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
-		if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0],
-		                             fuse ? w.hit[0] : nullptr, s)) return rc;
+		// LDS-resident scene: no generate pass, the first shade makes its own camera rays
+		if (fuse) {
+			if (!sequential) hipLaunchKernelGGL(k_sample_matrices, dim3(ns), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
+		} else if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
 		for (uint32_t b = 0; b < frame->depth; b++) {
 			int in = b & 1, out = in ^ 1;
 			if (!fuse)
@@ -996,7 +1032,8 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 			pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
 			if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
 			                          fuse ? w.hit[out] : nullptr, w.counts + (size_t)(b + 1) * G,
-			                          w.radiance, w.lit, sequential ? rng : nullptr, s)) return rc;
+			                          w.radiance, w.lit, sequential ? rng : nullptr, s,
+			                          fuse && b == 0 ? w.smat : nullptr, fuse && b == 0 ? rng : nullptr)) return rc;
 		}
 		hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
 		                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
