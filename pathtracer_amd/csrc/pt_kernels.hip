@@ -315,8 +315,13 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 // GEN (bounce 0 of an LDS-resident scene): the bounce-0 queue is never materialised -- the camera ray of slot q is
 // generated and intersected right here (a4 fused into its consumer), which takes generate's 24 B per path of writes
 // and this kernel's reads of them off the bus.
-template <bool FIRST, bool SCENE_LDS, bool EXTEND, bool GEN>
-__global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
+// RESOLVE (whole-pipeline driver, LDS-resident scene): the continuing ray's hit is known right here, so a path whose
+// next hit is terminal -- nothing, an emitter, or (REFERENCE shading) an absorber -- is finished by its producer and
+// never enters the queue: only paths that bounce again are written.  `lit` must then be zero when the pass starts (a
+// finished path writes only if it reached an emitter), and the rays traced for the next bounce are counted apart from
+// the queue's length (ray_count_out) because they are no longer the same number.
+template <bool FIRST, bool SCENE_LDS, bool EXTEND, bool GEN, bool RESOLVE>
+__global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
                                                   const float4* __restrict__ qa, const float4* __restrict__ qb,
                                                   const float4* __restrict__ qc, const uint32_t* __restrict__ qpid,
@@ -328,7 +333,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
                                                   uint32_t* __restrict__ count_out,
                                                   float4* __restrict__ radiance, unsigned char* __restrict__ lit,
                                                   uint32_t* __restrict__ rng_out,
-                                                  const uint32_t* __restrict__ smat, const uint32_t* __restrict__ rng_in) {
+                                                  const uint32_t* __restrict__ smat, const uint32_t* __restrict__ rng_in,
+                                                  uint32_t* __restrict__ ray_count_out) {
+	static_assert(!RESOLVE || EXTEND, "terminal next hits can only be resolved where the next hit is computed");
 	static_assert(!EXTEND || SCENE_LDS, "the fused extend intersects against the LDS copy of the scene");
 	static_assert(!GEN || (FIRST && EXTEND), "generation is fused into the first shade of an LDS-resident scene only");
 	extern __shared__ float4 s_scene[];
@@ -352,13 +359,28 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 	const uint32_t lane = threadIdx.x & 63u;
 	const bool extended = f.shading == PT_SHADING_EXTENDED;
 	__shared__ uint32_t s_out;            // this block's survivors so far
-	if (threadIdx.x == 0) s_out = 0;
+	__shared__ uint32_t s_traced;         // RESOLVE: rays this block traced for the next bounce
+	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
 	__syncthreads();
 
+	// the entry's hit (and path id) for the NEXT trip are requested before this trip's work: one trip is a chain of
+	// dependent loads otherwise, and at bounce >= 1 most lanes only set a flag, so the kernel ran at a quarter of the HBM rate
+	uint2 h_next = uint2{ 0u, kNoHit };
+	uint32_t pid_next = 0;
+	if (!GEN && count > 0) {
+		uint32_t q0 = queue_slot(0, G) + threadIdx.x;
+		if (threadIdx.x < count && q0 < capacity) { h_next = hit[q0]; if (!FIRST) pid_next = qpid[q0]; }
+	}
 	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
 		uint32_t q = queue_slot(j0, G) + threadIdx.x;
 		bool active = j0 + threadIdx.x < count && q < capacity;
-		bool cont = false;
+		uint2 h_cur = h_next;
+		uint32_t pid_cur = pid_next;
+		if (!GEN && j0 + kBlock < count) {
+			uint32_t qn = queue_slot(j0 + kBlock, G) + threadIdx.x;
+			if (j0 + kBlock + threadIdx.x < count && qn < capacity) { h_next = hit[qn]; if (!FIRST) pid_next = qpid[qn]; }
+		}
+		bool cont = false, traced = false;
 		float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
 		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
 		float t = 0.0f;
@@ -387,8 +409,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 				intersect_range_primary(tris, s_prim, n_tris, det_bounded, gd, best, ptri);
 				h = uint2{ __float_as_uint(best), ptri };
 				gen_b = float4{ gd.x, gd.y, gd.z, __uint_as_float(r0) };
-			} else h = hit[q];
-			if (!FIRST) pid = qpid[q];
+			} else h = h_cur;
+			if (!FIRST) pid = pid_cur;
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
 			uint32_t type = 0xFFFFFFFFu;
 			float4 color = float4{ 0, 0, 0, 0 };
@@ -420,6 +442,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 				else shade_diffuse(n, color, t, s_jump, o, d, step, rng);
 				cont = true;
 				if (EXTEND && !last_bounce) intersect_range(tris, 0, n_tris, det_bounded, o, d, t, next_tri);
+				if (RESOLVE) {
+					traced = !last_bounce;
+					cont = false;
+					if (!last_bounce && next_tri != kNoHit) {
+						uint32_t m2 = __float_as_uint(tris[4 * next_tri + 3].x);
+						uint32_t type2 = __float_as_uint(mats[2 * m2].x);
+						if (type2 == PT_MAT_EMISSIVE) {
+							float4 c2 = mats[2 * m2 + 1];
+							frame = float4{ step.x * c2.x, step.y * c2.y, step.z * c2.z, step.w * c2.w };     // :89, as the next shade would
+							emitted = true;
+						} else if (extended || type2 == PT_MAT_DIFFUSE) cont = true;
+						// REFERENCE, REFLECTIVE or unknown type: absorbed at the next bounce (:91-93), frame stays (0,0,0,1)
+					}
+				}
 			} else {
 				if (type == PT_MAT_EMISSIVE) {
 					if (!FIRST) step = qc[q];
@@ -431,10 +467,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 			}
 			if (!cont || last_bounce) {
 				// every path that ends sets its flag; only emitter hits carry a radiance, all others are (0,0,0,1)
-				lit[pid] = emitted ? 1 : 0;
+				if (!RESOLVE || emitted) lit[pid] = emitted ? 1 : 0;
 				if (emitted) radiance[pid] = frame;
 				if (rng_out) rng_out[pid] = rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
 			}
+		}
+		if (RESOLVE) {
+			uint32_t n_traced = (uint32_t)__popcll(__ballot(traced));
+			if (n_traced && lane == 0) atomicAdd(&s_traced, n_traced);
 		}
 		// wave64 compaction of the continuing paths: ballot + prefix, one LDS add per wave
 		unsigned long long mask = __ballot(cont);
@@ -455,7 +495,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameDev f, const unsigned cha
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) count_out[blockIdx.x] = s_out;
+	if (threadIdx.x == 0) {
+		count_out[blockIdx.x] = s_out;
+		if (RESOLVE) ray_count_out[blockIdx.x] = s_traced;
+	}
 }
 
 // a10. One thread per pixel, the pass's samples folded in order.
@@ -646,6 +689,7 @@ struct Workspace {
 	float4* radiance;
 	unsigned char* lit;  // 1 byte per path: 1 = radiance[] holds the sample, 0 = the sample is (0,0,0,1)
 	uint32_t* counts;    // (PT_MAX_DEPTH + 2) x G words: per bounce, per queue block
+	uint32_t* ray_counts; // same shape: rays traced per bounce, where terminal hits never enter the queue (k_shade RESOLVE)
 	uint32_t* smat;      // samples_per_pass x 32 words (STRIDED)
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -660,6 +704,7 @@ size_t carve(Workspace* w, unsigned char* base, size_t paths, uint32_t samples_p
 	w->radiance = (float4*)take(paths * 16);
 	w->lit = (unsigned char*)take(paths);
 	w->counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
+	w->ray_counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
 	w->smat = (uint32_t*)take((size_t)samples_per_pass * 32 * 4);
 	return off;
 }
@@ -941,7 +986,7 @@ int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob
 static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneInfo& si, uint32_t bounce,
                         pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
                         pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s,
-                        const uint32_t* gen_smat = nullptr, const uint32_t* gen_rng = nullptr) {
+                        const uint32_t* gen_smat = nullptr, const uint32_t* gen_rng = nullptr, uint32_t* ray_count_out = nullptr) {
 	uint32_t last = (bounce + 1 >= f.depth) ? 1u : 0u;
 	bool lds = shade_scene_in_lds(si);
 	bool extend = hit_out != nullptr;
@@ -950,12 +995,16 @@ static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneIn
 	if (gen && !(bounce == 0 && extend)) return fail(PT_ERR_INVALID, "shade: generation can only be fused into bounce 0 of an LDS-resident scene");
 	size_t lds_bytes = shade_lds_bytes(si) + (gen ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
 	dim3 grid(grid_for(capacity)), block(kBlock);
-#define PT_SHADE(FIRST, LDS, EXT, GEN) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT, GEN>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
+	bool resolve = ray_count_out != nullptr;
+	if (resolve && !extend) return fail(PT_ERR_INVALID, "shade: terminal hits are resolved only with the fused extend");
+#define PT_SHADE(FIRST, LDS, EXT, GEN) if (resolve) PT_SHADE_R(FIRST, LDS, EXT, GEN, (EXT)); else PT_SHADE_R(FIRST, LDS, EXT, GEN, false)
+#define PT_SHADE_R(FIRST, LDS, EXT, GEN, RES) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT, GEN, RES>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
 	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
-	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng, gen_smat, gen_rng)
+	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng, gen_smat, gen_rng, ray_count_out)
 	if (bounce == 0) { if (gen) PT_SHADE(true, true, true, true); else if (extend) PT_SHADE(true, true, true, false); else if (lds) PT_SHADE(true, true, false, false); else PT_SHADE(true, false, false, false); }
 	else { if (extend) PT_SHADE(false, true, true, false); else if (lds) PT_SHADE(false, true, false, false); else PT_SHADE(false, false, false, false); }
 #undef PT_SHADE
+#undef PT_SHADE_R
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
@@ -1021,8 +1070,11 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 		uint32_t ns = std::min(samples_per_pass, n_samples - done);
 		uint32_t paths = ns * frame->pixel_count;
 		hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
-		// LDS-resident scene: no generate pass, the first shade makes its own camera rays
+		// LDS-resident scene: no generate pass, the first shade makes its own camera rays, and every shade finishes the
+		// paths whose next hit is terminal (lit flags start at zero, rays are counted apart from the queue)
 		if (fuse) {
+			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.ray_counts, G, paths);
+			HIP_TRY(hipMemsetAsync(w.lit, 0, paths, s));
 			if (!sequential) hipLaunchKernelGGL(k_sample_matrices, dim3(ns), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
 		} else if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
 		for (uint32_t b = 0; b < frame->depth; b++) {
@@ -1033,11 +1085,12 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 			if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
 			                          fuse ? w.hit[out] : nullptr, w.counts + (size_t)(b + 1) * G,
 			                          w.radiance, w.lit, sequential ? rng : nullptr, s,
-			                          fuse && b == 0 ? w.smat : nullptr, fuse && b == 0 ? rng : nullptr)) return rc;
+			                          fuse && b == 0 ? w.smat : nullptr, fuse && b == 0 ? rng : nullptr,
+			                          fuse ? w.ray_counts + (size_t)(b + 1) * G : nullptr)) return rc;
 		}
 		hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
 		                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
-		if (stats) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.counts, G, frame->depth, (unsigned long long*)stats);
+		if (stats) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)(fuse ? w.ray_counts : w.counts), G, frame->depth, (unsigned long long*)stats);
 		HIP_TRY(hipGetLastError());
 	}
 	return PT_OK;
