@@ -312,6 +312,165 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 // rng word when the streams are written back), an emitter hit adds the throughput, only a diffuse
 // hit reads the ray.  EXTEND (scene in LDS): the new ray is intersected at once (a5+a6 fused into
 // the producer) and the hit stored with the continuing path, so no extend pass re-reads it.
+// What one block's shade of one bounce needs besides its queues.
+struct ShadeCtx {
+	const FrameDev& f;
+	const float4* tris; const float4* mats; const float4* s_prim; const uint32_t* s_jump;
+	uint32_t n_tris; bool det_bounded; uint32_t capacity;
+	float4* radiance; unsigned char* lit; uint32_t* rng_out;
+	const uint32_t* smat; const uint32_t* rng_in;
+	uint32_t* s_out; uint32_t* s_traced;       // LDS counters, zeroed (and a barrier passed) before the call
+};
+
+// One bounce of one block: shades the `count` entries of its input queue, compacts the paths that go on into its own
+// slots of the output queue; *c.s_out / *c.s_traced hold the counts afterwards (no barrier at the end).
+template <bool FIRST, bool EXTEND, bool GEN, bool RESOLVE>
+__device__ __forceinline__ void shade_block(const ShadeCtx& c, uint32_t last_bounce, uint32_t count,
+                                            const float4* __restrict__ qa, const float4* __restrict__ qb,
+                                            const float4* __restrict__ qc, const uint32_t* __restrict__ qpid,
+                                            const uint2* __restrict__ hit,
+                                            float4* __restrict__ oa, float4* __restrict__ ob,
+                                            float4* __restrict__ oc, uint32_t* __restrict__ opid,
+                                            uint2* __restrict__ ohit) {
+	const uint32_t G = gridDim.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool extended = c.f.shading == PT_SHADING_EXTENDED;
+	uint32_t& s_out = *c.s_out;           // this block's survivors so far (zeroed by the caller, barrier included)
+	uint32_t& s_traced = *c.s_traced;     // RESOLVE: rays this block traced for the next bounce
+
+	// the entry's hit (and path id) for the NEXT trip are requested before this trip's work: one trip is a chain of
+	// dependent loads otherwise, and at bounce >= 1 most lanes only set a flag, so the kernel ran at a quarter of the HBM rate
+	uint2 h_next = uint2{ 0u, kNoHit };
+	uint32_t pid_next = 0;
+	if (!GEN && count > 0) {
+		uint32_t q0 = queue_slot(0, G) + threadIdx.x;
+		if (threadIdx.x < count && q0 < c.capacity) { h_next = hit[q0]; if (!FIRST) pid_next = qpid[q0]; }
+	}
+	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
+		uint32_t q = queue_slot(j0, G) + threadIdx.x;
+		bool active = j0 + threadIdx.x < count && q < c.capacity;
+		uint2 h_cur = h_next;
+		uint32_t pid_cur = pid_next;
+		if (!GEN && j0 + kBlock < count) {
+			uint32_t qn = queue_slot(j0 + kBlock, G) + threadIdx.x;
+			if (j0 + kBlock + threadIdx.x < count && qn < c.capacity) { h_next = hit[qn]; if (!FIRST) pid_next = qpid[qn]; }
+		}
+		bool cont = false, traced = false;
+		float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
+		float t = 0.0f;
+		uint32_t rng = 0, pid = q, next_tri = kNoHit;
+		// GEN: which sample of the pass this slot belongs to decides the jump matrix; almost always one sample per wave
+		uint32_t gen_s = 0, gen_li = 0;
+		bool gen_uniform = true;
+		if (GEN) {
+			gen_s = active ? q / c.f.pixel_count : 0u;
+			gen_li = q - gen_s * c.f.pixel_count;
+			uint32_t s_first = __builtin_amdgcn_readfirstlane(active ? gen_s : 0xFFFFFFFFu);
+			gen_uniform = __ballot(active && gen_s != s_first) == 0ull;
+			if (gen_uniform && s_first != 0xFFFFFFFFu) gen_s = s_first;
+		}
+		if (active) {
+			uint2 h;
+			float4 gen_b = float4{ 0, 0, 0, 0 };
+			if (GEN) {
+				uint32_t i = c.f.pixel_first + gen_li;
+				uint32_t r0 = c.rng_in[gen_li];
+				if (c.f.rng_mode == PT_RNG_STRIDED) r0 = gen_uniform ? mat_apply(c.smat + 32u * __builtin_amdgcn_readfirstlane(gen_s), r0) : mat_apply(c.smat + 32u * gen_s, r0);
+				uint32_t px = i % (uint32_t)c.f.width, py = i / (uint32_t)c.f.width;
+				Vec3 gd = primary_direction(c.f, px, py, r0);
+				float best = FLT_MAX;
+				uint32_t ptri = kNoHit;
+				intersect_range_primary(c.tris, c.s_prim, c.n_tris, c.det_bounded, gd, best, ptri);
+				h = uint2{ __float_as_uint(best), ptri };
+				gen_b = float4{ gd.x, gd.y, gd.z, __uint_as_float(r0) };
+			} else h = h_cur;
+			if (!FIRST) pid = pid_cur;
+			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
+			uint32_t type = 0xFFFFFFFFu;
+			float4 color = float4{ 0, 0, 0, 0 };
+			float reflectivity = 0.0f;
+			Vec3 n{ 0, 0, 0 };
+			if (h.y != kNoHit) {
+				float4 r2 = c.tris[4 * h.y + 2], r3 = c.tris[4 * h.y + 3];
+				uint32_t m = __float_as_uint(r3.x);
+				float4 head = c.mats[2 * m];
+				type = __float_as_uint(head.x);
+				reflectivity = head.y;
+				color = c.mats[2 * m + 1];
+				n = Vec3{ r2.y, r2.z, r2.w };
+			}
+			bool emitted = false;
+			// REFERENCE: only DIFFUSE continues (kernels.cu:79-93); EXTENDED: every hit that is not an emitter does
+			if (type == PT_MAT_DIFFUSE || (extended && h.y != kNoHit && type != PT_MAT_EMISSIVE)) {
+				float4 b = GEN ? gen_b : qb[q];
+				if (FIRST) {
+					o = Vec3{ c.f.origin.x, c.f.origin.y, c.f.origin.z }; d = Vec3{ b.x, b.y, b.z };
+				} else {
+					float4 a = qa[q];
+					step = qc[q];
+					o = Vec3{ a.x, a.y, a.z }; d = Vec3{ a.w, b.x, b.y };
+				}
+				t = __uint_as_float(h.x);
+				rng = __float_as_uint(b.w);
+				if (extended) { shade_extended(type, n, color, reflectivity, t, o, d, step, rng); t = FLT_MAX; }   // the next bounce finds its own closest hit
+				else shade_diffuse(n, color, t, c.s_jump, o, d, step, rng);
+				cont = true;
+				if (EXTEND && !last_bounce) intersect_range(c.tris, 0, c.n_tris, c.det_bounded, o, d, t, next_tri);
+				if (RESOLVE) {
+					traced = !last_bounce;
+					cont = false;
+					if (!last_bounce && next_tri != kNoHit) {
+						uint32_t m2 = __float_as_uint(c.tris[4 * next_tri + 3].x);
+						uint32_t type2 = __float_as_uint(c.mats[2 * m2].x);
+						if (type2 == PT_MAT_EMISSIVE) {
+							float4 c2 = c.mats[2 * m2 + 1];
+							frame = float4{ step.x * c2.x, step.y * c2.y, step.z * c2.z, step.w * c2.w };     // :89, as the next shade would
+							emitted = true;
+						} else if (extended || type2 == PT_MAT_DIFFUSE) cont = true;
+						// REFERENCE, REFLECTIVE or unknown type: absorbed at the next bounce (:91-93), frame stays (0,0,0,1)
+					}
+				}
+			} else {
+				if (type == PT_MAT_EMISSIVE) {
+					if (!FIRST) step = qc[q];
+					frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };  // :89
+					emitted = true;
+				}
+				// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
+				if (c.rng_out) rng = __float_as_uint(GEN ? gen_b.w : qb[q].w);
+			}
+			if (!cont || last_bounce) {
+				// every path that ends sets its flag; only emitter hits carry a c.radiance, all others are (0,0,0,1)
+				if (!RESOLVE || emitted) c.lit[pid] = emitted ? 1 : 0;
+				if (emitted) c.radiance[pid] = frame;
+				if (c.rng_out) c.rng_out[pid] = rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
+			}
+		}
+		if (RESOLVE) {
+			uint32_t n_traced = (uint32_t)__popcll(__ballot(traced));
+			if (n_traced && lane == 0) atomicAdd(&s_traced, n_traced);
+		}
+		// wave64 compaction of the continuing paths: ballot + prefix, one LDS add per wave
+		unsigned long long mask = __ballot(cont);
+		uint32_t n_cont = (uint32_t)__popcll(mask);
+		if (n_cont) {
+			uint32_t wave_base = 0;
+			if (lane == 0) wave_base = atomicAdd(&s_out, n_cont);
+			wave_base = __shfl(wave_base, 0, 64);
+			if (cont && !last_bounce) {
+				uint32_t j = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+				uint32_t pos = ((j / kBlock) * G + blockIdx.x) * kBlock + (j % kBlock);
+				oa[pos] = float4{ o.x, o.y, o.z, d.x };
+				ob[pos] = float4{ d.y, d.z, t, __uint_as_float(rng) };
+				oc[pos] = step;
+				opid[pos] = pid;
+				if (EXTEND) ohit[pos] = uint2{ __float_as_uint(t), next_tri };
+			}
+		}
+	}
+}
+
 // GEN (bounce 0 of an LDS-resident scene): the bounce-0 queue is never materialised -- the camera ray of slot q is
 // generated and intersected right here (a4 fused into its consumer), which takes generate's 24 B per path of writes
 // and this kernel's reads of them off the bus.
@@ -354,150 +513,67 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 		if (GEN) stage_primary_records(g_tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_scene + nt4 + nm2);
 	}
 	const float4* s_prim = s_scene + n_tris * 4 + n_mats * 2;
-	const uint32_t G = gridDim.x;
-	const uint32_t count = count_ptr[blockIdx.x];
-	const uint32_t lane = threadIdx.x & 63u;
-	const bool extended = f.shading == PT_SHADING_EXTENDED;
-	__shared__ uint32_t s_out;            // this block's survivors so far
-	__shared__ uint32_t s_traced;         // RESOLVE: rays this block traced for the next bounce
+	__shared__ uint32_t s_out, s_traced;
 	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
 	__syncthreads();
-
-	// the entry's hit (and path id) for the NEXT trip are requested before this trip's work: one trip is a chain of
-	// dependent loads otherwise, and at bounce >= 1 most lanes only set a flag, so the kernel ran at a quarter of the HBM rate
-	uint2 h_next = uint2{ 0u, kNoHit };
-	uint32_t pid_next = 0;
-	if (!GEN && count > 0) {
-		uint32_t q0 = queue_slot(0, G) + threadIdx.x;
-		if (threadIdx.x < count && q0 < capacity) { h_next = hit[q0]; if (!FIRST) pid_next = qpid[q0]; }
-	}
-	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
-		uint32_t q = queue_slot(j0, G) + threadIdx.x;
-		bool active = j0 + threadIdx.x < count && q < capacity;
-		uint2 h_cur = h_next;
-		uint32_t pid_cur = pid_next;
-		if (!GEN && j0 + kBlock < count) {
-			uint32_t qn = queue_slot(j0 + kBlock, G) + threadIdx.x;
-			if (j0 + kBlock + threadIdx.x < count && qn < capacity) { h_next = hit[qn]; if (!FIRST) pid_next = qpid[qn]; }
-		}
-		bool cont = false, traced = false;
-		float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
-		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
-		float t = 0.0f;
-		uint32_t rng = 0, pid = q, next_tri = kNoHit;
-		// GEN: which sample of the pass this slot belongs to decides the jump matrix; almost always one sample per wave
-		uint32_t gen_s = 0, gen_li = 0;
-		bool gen_uniform = true;
-		if (GEN) {
-			gen_s = active ? q / f.pixel_count : 0u;
-			gen_li = q - gen_s * f.pixel_count;
-			uint32_t s_first = __builtin_amdgcn_readfirstlane(active ? gen_s : 0xFFFFFFFFu);
-			gen_uniform = __ballot(active && gen_s != s_first) == 0ull;
-			if (gen_uniform && s_first != 0xFFFFFFFFu) gen_s = s_first;
-		}
-		if (active) {
-			uint2 h;
-			float4 gen_b = float4{ 0, 0, 0, 0 };
-			if (GEN) {
-				uint32_t i = f.pixel_first + gen_li;
-				uint32_t r0 = rng_in[gen_li];
-				if (f.rng_mode == PT_RNG_STRIDED) r0 = gen_uniform ? mat_apply(smat + 32u * __builtin_amdgcn_readfirstlane(gen_s), r0) : mat_apply(smat + 32u * gen_s, r0);
-				uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
-				Vec3 gd = primary_direction(f, px, py, r0);
-				float best = FLT_MAX;
-				uint32_t ptri = kNoHit;
-				intersect_range_primary(tris, s_prim, n_tris, det_bounded, gd, best, ptri);
-				h = uint2{ __float_as_uint(best), ptri };
-				gen_b = float4{ gd.x, gd.y, gd.z, __uint_as_float(r0) };
-			} else h = h_cur;
-			if (!FIRST) pid = pid_cur;
-			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
-			uint32_t type = 0xFFFFFFFFu;
-			float4 color = float4{ 0, 0, 0, 0 };
-			float reflectivity = 0.0f;
-			Vec3 n{ 0, 0, 0 };
-			if (h.y != kNoHit) {
-				float4 r2 = tris[4 * h.y + 2], r3 = tris[4 * h.y + 3];
-				uint32_t m = __float_as_uint(r3.x);
-				float4 head = mats[2 * m];
-				type = __float_as_uint(head.x);
-				reflectivity = head.y;
-				color = mats[2 * m + 1];
-				n = Vec3{ r2.y, r2.z, r2.w };
-			}
-			bool emitted = false;
-			// REFERENCE: only DIFFUSE continues (kernels.cu:79-93); EXTENDED: every hit that is not an emitter does
-			if (type == PT_MAT_DIFFUSE || (extended && h.y != kNoHit && type != PT_MAT_EMISSIVE)) {
-				float4 b = GEN ? gen_b : qb[q];
-				if (FIRST) {
-					o = Vec3{ f.origin.x, f.origin.y, f.origin.z }; d = Vec3{ b.x, b.y, b.z };
-				} else {
-					float4 a = qa[q];
-					step = qc[q];
-					o = Vec3{ a.x, a.y, a.z }; d = Vec3{ a.w, b.x, b.y };
-				}
-				t = __uint_as_float(h.x);
-				rng = __float_as_uint(b.w);
-				if (extended) { shade_extended(type, n, color, reflectivity, t, o, d, step, rng); t = FLT_MAX; }   // the next bounce finds its own closest hit
-				else shade_diffuse(n, color, t, s_jump, o, d, step, rng);
-				cont = true;
-				if (EXTEND && !last_bounce) intersect_range(tris, 0, n_tris, det_bounded, o, d, t, next_tri);
-				if (RESOLVE) {
-					traced = !last_bounce;
-					cont = false;
-					if (!last_bounce && next_tri != kNoHit) {
-						uint32_t m2 = __float_as_uint(tris[4 * next_tri + 3].x);
-						uint32_t type2 = __float_as_uint(mats[2 * m2].x);
-						if (type2 == PT_MAT_EMISSIVE) {
-							float4 c2 = mats[2 * m2 + 1];
-							frame = float4{ step.x * c2.x, step.y * c2.y, step.z * c2.z, step.w * c2.w };     // :89, as the next shade would
-							emitted = true;
-						} else if (extended || type2 == PT_MAT_DIFFUSE) cont = true;
-						// REFERENCE, REFLECTIVE or unknown type: absorbed at the next bounce (:91-93), frame stays (0,0,0,1)
-					}
-				}
-			} else {
-				if (type == PT_MAT_EMISSIVE) {
-					if (!FIRST) step = qc[q];
-					frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };  // :89
-					emitted = true;
-				}
-				// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
-				if (rng_out) rng = __float_as_uint(GEN ? gen_b.w : qb[q].w);
-			}
-			if (!cont || last_bounce) {
-				// every path that ends sets its flag; only emitter hits carry a radiance, all others are (0,0,0,1)
-				if (!RESOLVE || emitted) lit[pid] = emitted ? 1 : 0;
-				if (emitted) radiance[pid] = frame;
-				if (rng_out) rng_out[pid] = rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
-			}
-		}
-		if (RESOLVE) {
-			uint32_t n_traced = (uint32_t)__popcll(__ballot(traced));
-			if (n_traced && lane == 0) atomicAdd(&s_traced, n_traced);
-		}
-		// wave64 compaction of the continuing paths: ballot + prefix, one LDS add per wave
-		unsigned long long mask = __ballot(cont);
-		uint32_t n_cont = (uint32_t)__popcll(mask);
-		if (n_cont) {
-			uint32_t wave_base = 0;
-			if (lane == 0) wave_base = atomicAdd(&s_out, n_cont);
-			wave_base = __shfl(wave_base, 0, 64);
-			if (cont && !last_bounce) {
-				uint32_t j = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-				uint32_t pos = ((j / kBlock) * G + blockIdx.x) * kBlock + (j % kBlock);
-				oa[pos] = float4{ o.x, o.y, o.z, d.x };
-				ob[pos] = float4{ d.y, d.z, t, __uint_as_float(rng) };
-				oc[pos] = step;
-				opid[pos] = pid;
-				if (EXTEND) ohit[pos] = uint2{ __float_as_uint(t), next_tri };
-			}
-		}
-	}
+	ShadeCtx c{ f, tris, mats, s_prim, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, smat, rng_in, &s_out, &s_traced };
+	shade_block<FIRST, EXTEND, GEN, RESOLVE>(c, last_bounce, count_ptr[blockIdx.x], qa, qb, qc, qpid, hit, oa, ob, oc, opid, ohit);
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		count_out[blockIdx.x] = s_out;
 		if (RESOLVE) ray_count_out[blockIdx.x] = s_traced;
+	}
+}
+
+// The whole bounce loop of a pass in ONE launch (LDS-resident scene).  Queue slots are owned block by block, so the paths
+// a block queues at bounce b are exactly the ones it shades at bounce b+1: nothing is exchanged between blocks and the
+// reference's per-bounce launches (PathTracer.cu:129-151) need no grid-wide barrier here -- a block barrier between
+// bounces is enough (the waves of a block share the CU's L1, so its own stores are visible to it after __syncthreads).
+// Bounce 0 generates its camera rays (GEN); terminal next hits are resolved by their producer (RESOLVE); the per-bounce
+// counters are still written, for the statistics.
+__global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
+                                                       float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
+                                                       float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
+                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ ray_counts, uint32_t capacity,
+                                                       float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out,
+                                                       const uint32_t* __restrict__ smat, const uint32_t* __restrict__ rng_in) {
+	extern __shared__ float4 s_scene[];
+	__shared__ uint32_t s_jump[1024];
+	__shared__ uint32_t s_out, s_traced;
+	stage_jump31(s_jump);
+	const bool det_bounded = scene_det_bounded(scene);
+	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
+	const float4* g_mats = g_tris + (size_t)n_tris * 4;
+	uint32_t nt4 = n_tris * 4, nm2 = n_mats * 2;
+	for (uint32_t k = threadIdx.x; k < nt4; k += kBlock) s_scene[k] = g_tris[k];
+	for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = g_mats[k];
+	stage_primary_records(g_tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_scene + nt4 + nm2);
+	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
+	__syncthreads();
+	ShadeCtx c{ f, s_scene, s_scene + nt4, s_scene + nt4 + nm2, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, smat, rng_in, &s_out, &s_traced };
+	const uint32_t G = gridDim.x;
+	uint32_t count = counts[blockIdx.x];                     // bounce 0: this block's share of the identity slots (k_set_count)
+	shade_block<true, true, true, true>(c, f.depth <= 1u ? 1u : 0u, count, nullptr, nullptr, nullptr, nullptr, nullptr, a1, b1, c1, pid1, hit1);
+	for (uint32_t b = 1;; b++) {
+		__syncthreads();
+		count = s_out;
+		uint32_t traced = s_traced;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			counts[(size_t)b * G + blockIdx.x] = count;
+			ray_counts[(size_t)b * G + blockIdx.x] = traced;
+			s_out = 0; s_traced = 0;
+		}
+		__syncthreads();
+		if (b >= f.depth) break;
+		if (count == 0) {                                       // nothing left: the remaining rows are zero
+			if (threadIdx.x == 0)
+				for (uint32_t r = b + 1; r <= f.depth; r++) { counts[(size_t)r * G + blockIdx.x] = 0; ray_counts[(size_t)r * G + blockIdx.x] = 0; }
+			break;
+		}
+		uint32_t last = b + 1 >= f.depth ? 1u : 0u;
+		if (b & 1u) shade_block<false, true, false, true>(c, last, count, a1, b1, c1, pid1, hit1, a0, b0, c0, pid0, hit0);
+		else shade_block<false, true, false, true>(c, last, count, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1);
 	}
 }
 
@@ -1077,7 +1153,15 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 			HIP_TRY(hipMemsetAsync(w.lit, 0, paths, s));
 			if (!sequential) hipLaunchKernelGGL(k_sample_matrices, dim3(ns), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
 		} else if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
-		for (uint32_t b = 0; b < frame->depth; b++) {
+		if (fuse) {
+			// one launch for the whole bounce loop: queue slots are block-private, so no stage waits for another block
+			size_t lds_bytes = shade_lds_bytes(si) + (size_t)si.n_tris * sizeof(PrimRec);
+			hipLaunchKernelGGL(k_bounces, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats,
+			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1],
+			                   w.counts, w.ray_counts, (uint32_t)paths_cap, w.radiance, w.lit, sequential ? rng : nullptr,
+			                   (const uint32_t*)w.smat, (const uint32_t*)rng);
+		}
+		for (uint32_t b = 0; !fuse && b < frame->depth; b++) {
 			int in = b & 1, out = in ^ 1;
 			if (!fuse)
 				launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
