@@ -315,16 +315,124 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 // What one block's shade of one bounce needs besides its queues.
 struct ShadeCtx {
 	const FrameDev& f;
-	const float4* tris; const float4* mats; const float4* s_prim; const uint32_t* s_jump;
+	const float4* tris; const float4* mats; const uint32_t* s_jump;
 	uint32_t n_tris; bool det_bounded; uint32_t capacity;
 	float4* radiance; unsigned char* lit; uint32_t* rng_out;
-	const uint32_t* smat; const uint32_t* rng_in;
 	uint32_t* s_out; uint32_t* s_traced;       // LDS counters, zeroed (and a barrier passed) before the call
 };
 
+// What a lane hands to the compaction: the path as the next bounce will read it.
+struct PathNext {
+	bool cont = false, traced = false;
+	float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
+	float t = 0.0f;
+	uint32_t rng = 0, pid = 0, next_tri = kNoHit;
+};
+
+// One lane, one path: the hit h of slot q is shaded (kernels.cu:44-96).  GEN: the camera ray was made by the caller
+// (gen_b = direction + rng word) and no queue is read.  RESOLVE (needs EXTEND): the continuing ray's hit is known right
+// here, so a path whose next hit is terminal -- nothing, an emitter, or (REFERENCE shading) an absorber -- is finished by
+// its producer and never enters the queue; `lit` must then be zero when the pass starts (a finished path writes only if
+// it reached an emitter).
+template <bool FIRST, bool EXTEND, bool GEN, bool RESOLVE>
+__device__ __forceinline__ void shade_lane(const ShadeCtx& c, bool extended, uint32_t last_bounce, uint32_t q, uint2 h, float4 gen_b,
+                                           const float4* __restrict__ qa, const float4* __restrict__ qb, const float4* __restrict__ qc,
+                                           PathNext& r) {
+	float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
+	uint32_t type = 0xFFFFFFFFu;
+	float4 color = float4{ 0, 0, 0, 0 };
+	float reflectivity = 0.0f;
+	Vec3 n{ 0, 0, 0 };
+	if (h.y != kNoHit) {
+		float4 r2 = c.tris[4 * h.y + 2], r3 = c.tris[4 * h.y + 3];
+		uint32_t m = __float_as_uint(r3.x);
+		float4 head = c.mats[2 * m];
+		type = __float_as_uint(head.x);
+		reflectivity = head.y;
+		color = c.mats[2 * m + 1];
+		n = Vec3{ r2.y, r2.z, r2.w };
+	}
+	bool emitted = false;
+	// REFERENCE: only DIFFUSE continues (kernels.cu:79-93); EXTENDED: every hit that is not an emitter does
+	if (type == PT_MAT_DIFFUSE || (extended && h.y != kNoHit && type != PT_MAT_EMISSIVE)) {
+		float4 b = GEN ? gen_b : qb[q];
+		if (FIRST) {
+			r.o = Vec3{ c.f.origin.x, c.f.origin.y, c.f.origin.z }; r.d = Vec3{ b.x, b.y, b.z };
+		} else {
+			float4 a = qa[q];
+			r.step = qc[q];
+			r.o = Vec3{ a.x, a.y, a.z }; r.d = Vec3{ a.w, b.x, b.y };
+		}
+		r.t = __uint_as_float(h.x);
+		r.rng = __float_as_uint(b.w);
+		if (extended) { shade_extended(type, n, color, reflectivity, r.t, r.o, r.d, r.step, r.rng); r.t = FLT_MAX; }   // the next bounce finds its own closest hit
+		else shade_diffuse(n, color, r.t, c.s_jump, r.o, r.d, r.step, r.rng);
+		r.cont = true;
+		if (EXTEND && !last_bounce) intersect_range(c.tris, 0, c.n_tris, c.det_bounded, r.o, r.d, r.t, r.next_tri);
+		if (RESOLVE) {
+			r.traced = !last_bounce;
+			r.cont = false;
+			if (!last_bounce && r.next_tri != kNoHit) {
+				uint32_t m2 = __float_as_uint(c.tris[4 * r.next_tri + 3].x);
+				uint32_t type2 = __float_as_uint(c.mats[2 * m2].x);
+				if (type2 == PT_MAT_EMISSIVE) {
+					float4 c2 = c.mats[2 * m2 + 1];
+					frame = float4{ r.step.x * c2.x, r.step.y * c2.y, r.step.z * c2.z, r.step.w * c2.w };     // :89, as the next shade would
+					emitted = true;
+				} else if (extended || type2 == PT_MAT_DIFFUSE) r.cont = true;
+				// REFERENCE, REFLECTIVE or unknown type: absorbed at the next bounce (:91-93), frame stays (0,0,0,1)
+			}
+		}
+	} else {
+		if (type == PT_MAT_EMISSIVE) {
+			if (!FIRST) r.step = qc[q];
+			frame = float4{ r.step.x * color.x, r.step.y * color.y, r.step.z * color.z, r.step.w * color.w };  // :89
+			emitted = true;
+		}
+		// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
+		if (c.rng_out) r.rng = __float_as_uint(GEN ? gen_b.w : qb[q].w);
+	}
+	if (!r.cont || last_bounce) {
+		// every path that ends sets its flag; only emitter hits carry a radiance, all others are (0,0,0,1)
+		if (!RESOLVE || emitted) c.lit[r.pid] = emitted ? 1 : 0;
+		if (emitted) c.radiance[r.pid] = frame;
+		if (c.rng_out) c.rng_out[r.pid] = r.rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
+	}
+}
+
+// wave64 compaction of the continuing paths into this block's own slots of the output queue: ballot + prefix, one LDS
+// add per wave.  Every lane of the wave calls it.
+template <bool EXTEND, bool RESOLVE>
+__device__ __forceinline__ void queue_push(const ShadeCtx& c, uint32_t last_bounce, const PathNext& r,
+                                           float4* __restrict__ oa, float4* __restrict__ ob, float4* __restrict__ oc,
+                                           uint32_t* __restrict__ opid, uint2* __restrict__ ohit) {
+	const uint32_t lane = threadIdx.x & 63u;
+	if (RESOLVE) {
+		uint32_t n_traced = (uint32_t)__popcll(__ballot(r.traced));
+		if (n_traced && lane == 0) atomicAdd(c.s_traced, n_traced);
+	}
+	unsigned long long mask = __ballot(r.cont);
+	uint32_t n_cont = (uint32_t)__popcll(mask);
+	if (n_cont) {
+		uint32_t wave_base = 0;
+		if (lane == 0) wave_base = atomicAdd(c.s_out, n_cont);
+		wave_base = __shfl(wave_base, 0, 64);
+		if (r.cont && !last_bounce) {
+			uint32_t j = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+			uint32_t pos = ((j / kBlock) * gridDim.x + blockIdx.x) * kBlock + (j % kBlock);
+			oa[pos] = float4{ r.o.x, r.o.y, r.o.z, r.d.x };
+			ob[pos] = float4{ r.d.y, r.d.z, r.t, __uint_as_float(r.rng) };
+			oc[pos] = r.step;
+			opid[pos] = r.pid;
+			if (EXTEND) ohit[pos] = uint2{ __float_as_uint(r.t), r.next_tri };
+		}
+	}
+}
+
 // One bounce of one block: shades the `count` entries of its input queue, compacts the paths that go on into its own
 // slots of the output queue; *c.s_out / *c.s_traced hold the counts afterwards (no barrier at the end).
-template <bool FIRST, bool EXTEND, bool GEN, bool RESOLVE>
+template <bool FIRST, bool EXTEND, bool RESOLVE>
 __device__ __forceinline__ void shade_block(const ShadeCtx& c, uint32_t last_bounce, uint32_t count,
                                             const float4* __restrict__ qa, const float4* __restrict__ qb,
                                             const float4* __restrict__ qc, const uint32_t* __restrict__ qpid,
@@ -333,16 +441,12 @@ __device__ __forceinline__ void shade_block(const ShadeCtx& c, uint32_t last_bou
                                             float4* __restrict__ oc, uint32_t* __restrict__ opid,
                                             uint2* __restrict__ ohit) {
 	const uint32_t G = gridDim.x;
-	const uint32_t lane = threadIdx.x & 63u;
 	const bool extended = c.f.shading == PT_SHADING_EXTENDED;
-	uint32_t& s_out = *c.s_out;           // this block's survivors so far (zeroed by the caller, barrier included)
-	uint32_t& s_traced = *c.s_traced;     // RESOLVE: rays this block traced for the next bounce
-
 	// the entry's hit (and path id) for the NEXT trip are requested before this trip's work: one trip is a chain of
 	// dependent loads otherwise, and at bounce >= 1 most lanes only set a flag, so the kernel ran at a quarter of the HBM rate
 	uint2 h_next = uint2{ 0u, kNoHit };
 	uint32_t pid_next = 0;
-	if (!GEN && count > 0) {
+	if (count > 0) {
 		uint32_t q0 = queue_slot(0, G) + threadIdx.x;
 		if (threadIdx.x < count && q0 < c.capacity) { h_next = hit[q0]; if (!FIRST) pid_next = qpid[q0]; }
 	}
@@ -351,135 +455,18 @@ __device__ __forceinline__ void shade_block(const ShadeCtx& c, uint32_t last_bou
 		bool active = j0 + threadIdx.x < count && q < c.capacity;
 		uint2 h_cur = h_next;
 		uint32_t pid_cur = pid_next;
-		if (!GEN && j0 + kBlock < count) {
+		if (j0 + kBlock < count) {
 			uint32_t qn = queue_slot(j0 + kBlock, G) + threadIdx.x;
 			if (j0 + kBlock + threadIdx.x < count && qn < c.capacity) { h_next = hit[qn]; if (!FIRST) pid_next = qpid[qn]; }
 		}
-		bool cont = false, traced = false;
-		float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
-		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
-		float t = 0.0f;
-		uint32_t rng = 0, pid = q, next_tri = kNoHit;
-		// GEN: which sample of the pass this slot belongs to decides the jump matrix; almost always one sample per wave
-		uint32_t gen_s = 0, gen_li = 0;
-		bool gen_uniform = true;
-		if (GEN) {
-			gen_s = active ? q / c.f.pixel_count : 0u;
-			gen_li = q - gen_s * c.f.pixel_count;
-			uint32_t s_first = __builtin_amdgcn_readfirstlane(active ? gen_s : 0xFFFFFFFFu);
-			gen_uniform = __ballot(active && gen_s != s_first) == 0ull;
-			if (gen_uniform && s_first != 0xFFFFFFFFu) gen_s = s_first;
-		}
-		if (active) {
-			uint2 h;
-			float4 gen_b = float4{ 0, 0, 0, 0 };
-			if (GEN) {
-				uint32_t i = c.f.pixel_first + gen_li;
-				uint32_t r0 = c.rng_in[gen_li];
-				if (c.f.rng_mode == PT_RNG_STRIDED) r0 = gen_uniform ? mat_apply(c.smat + 32u * __builtin_amdgcn_readfirstlane(gen_s), r0) : mat_apply(c.smat + 32u * gen_s, r0);
-				uint32_t px = i % (uint32_t)c.f.width, py = i / (uint32_t)c.f.width;
-				Vec3 gd = primary_direction(c.f, px, py, r0);
-				float best = FLT_MAX;
-				uint32_t ptri = kNoHit;
-				intersect_range_primary(c.tris, c.s_prim, c.n_tris, c.det_bounded, gd, best, ptri);
-				h = uint2{ __float_as_uint(best), ptri };
-				gen_b = float4{ gd.x, gd.y, gd.z, __uint_as_float(r0) };
-			} else h = h_cur;
-			if (!FIRST) pid = pid_cur;
-			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
-			uint32_t type = 0xFFFFFFFFu;
-			float4 color = float4{ 0, 0, 0, 0 };
-			float reflectivity = 0.0f;
-			Vec3 n{ 0, 0, 0 };
-			if (h.y != kNoHit) {
-				float4 r2 = c.tris[4 * h.y + 2], r3 = c.tris[4 * h.y + 3];
-				uint32_t m = __float_as_uint(r3.x);
-				float4 head = c.mats[2 * m];
-				type = __float_as_uint(head.x);
-				reflectivity = head.y;
-				color = c.mats[2 * m + 1];
-				n = Vec3{ r2.y, r2.z, r2.w };
-			}
-			bool emitted = false;
-			// REFERENCE: only DIFFUSE continues (kernels.cu:79-93); EXTENDED: every hit that is not an emitter does
-			if (type == PT_MAT_DIFFUSE || (extended && h.y != kNoHit && type != PT_MAT_EMISSIVE)) {
-				float4 b = GEN ? gen_b : qb[q];
-				if (FIRST) {
-					o = Vec3{ c.f.origin.x, c.f.origin.y, c.f.origin.z }; d = Vec3{ b.x, b.y, b.z };
-				} else {
-					float4 a = qa[q];
-					step = qc[q];
-					o = Vec3{ a.x, a.y, a.z }; d = Vec3{ a.w, b.x, b.y };
-				}
-				t = __uint_as_float(h.x);
-				rng = __float_as_uint(b.w);
-				if (extended) { shade_extended(type, n, color, reflectivity, t, o, d, step, rng); t = FLT_MAX; }   // the next bounce finds its own closest hit
-				else shade_diffuse(n, color, t, c.s_jump, o, d, step, rng);
-				cont = true;
-				if (EXTEND && !last_bounce) intersect_range(c.tris, 0, c.n_tris, c.det_bounded, o, d, t, next_tri);
-				if (RESOLVE) {
-					traced = !last_bounce;
-					cont = false;
-					if (!last_bounce && next_tri != kNoHit) {
-						uint32_t m2 = __float_as_uint(c.tris[4 * next_tri + 3].x);
-						uint32_t type2 = __float_as_uint(c.mats[2 * m2].x);
-						if (type2 == PT_MAT_EMISSIVE) {
-							float4 c2 = c.mats[2 * m2 + 1];
-							frame = float4{ step.x * c2.x, step.y * c2.y, step.z * c2.z, step.w * c2.w };     // :89, as the next shade would
-							emitted = true;
-						} else if (extended || type2 == PT_MAT_DIFFUSE) cont = true;
-						// REFERENCE, REFLECTIVE or unknown type: absorbed at the next bounce (:91-93), frame stays (0,0,0,1)
-					}
-				}
-			} else {
-				if (type == PT_MAT_EMISSIVE) {
-					if (!FIRST) step = qc[q];
-					frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };  // :89
-					emitted = true;
-				}
-				// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
-				if (c.rng_out) rng = __float_as_uint(GEN ? gen_b.w : qb[q].w);
-			}
-			if (!cont || last_bounce) {
-				// every path that ends sets its flag; only emitter hits carry a c.radiance, all others are (0,0,0,1)
-				if (!RESOLVE || emitted) c.lit[pid] = emitted ? 1 : 0;
-				if (emitted) c.radiance[pid] = frame;
-				if (c.rng_out) c.rng_out[pid] = rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
-			}
-		}
-		if (RESOLVE) {
-			uint32_t n_traced = (uint32_t)__popcll(__ballot(traced));
-			if (n_traced && lane == 0) atomicAdd(&s_traced, n_traced);
-		}
-		// wave64 compaction of the continuing paths: ballot + prefix, one LDS add per wave
-		unsigned long long mask = __ballot(cont);
-		uint32_t n_cont = (uint32_t)__popcll(mask);
-		if (n_cont) {
-			uint32_t wave_base = 0;
-			if (lane == 0) wave_base = atomicAdd(&s_out, n_cont);
-			wave_base = __shfl(wave_base, 0, 64);
-			if (cont && !last_bounce) {
-				uint32_t j = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-				uint32_t pos = ((j / kBlock) * G + blockIdx.x) * kBlock + (j % kBlock);
-				oa[pos] = float4{ o.x, o.y, o.z, d.x };
-				ob[pos] = float4{ d.y, d.z, t, __uint_as_float(rng) };
-				oc[pos] = step;
-				opid[pos] = pid;
-				if (EXTEND) ohit[pos] = uint2{ __float_as_uint(t), next_tri };
-			}
-		}
+		PathNext r;
+		r.pid = FIRST ? q : pid_cur;
+		if (active) shade_lane<FIRST, EXTEND, false, RESOLVE>(c, extended, last_bounce, q, h_cur, float4{ 0, 0, 0, 0 }, qa, qb, qc, r);
+		queue_push<EXTEND, RESOLVE>(c, last_bounce, r, oa, ob, oc, opid, ohit);
 	}
 }
 
-// GEN (bounce 0 of an LDS-resident scene): the bounce-0 queue is never materialised -- the camera ray of slot q is
-// generated and intersected right here (a4 fused into its consumer), which takes generate's 24 B per path of writes
-// and this kernel's reads of them off the bus.
-// RESOLVE (whole-pipeline driver, LDS-resident scene): the continuing ray's hit is known right here, so a path whose
-// next hit is terminal -- nothing, an emitter, or (REFERENCE shading) an absorber -- is finished by its producer and
-// never enters the queue: only paths that bounce again are written.  `lit` must then be zero when the pass starts (a
-// finished path writes only if it reached an emitter), and the rays traced for the next bounce are counted apart from
-// the queue's length (ray_count_out) because they are no longer the same number.
-template <bool FIRST, bool SCENE_LDS, bool EXTEND, bool GEN, bool RESOLVE>
+template <bool FIRST, bool SCENE_LDS, bool EXTEND>
 __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
                                                   const float4* __restrict__ qa, const float4* __restrict__ qb,
@@ -491,12 +478,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
                                                   uint2* __restrict__ ohit,
                                                   uint32_t* __restrict__ count_out,
                                                   float4* __restrict__ radiance, unsigned char* __restrict__ lit,
-                                                  uint32_t* __restrict__ rng_out,
-                                                  const uint32_t* __restrict__ smat, const uint32_t* __restrict__ rng_in,
-                                                  uint32_t* __restrict__ ray_count_out) {
-	static_assert(!RESOLVE || EXTEND, "terminal next hits can only be resolved where the next hit is computed");
+                                                  uint32_t* __restrict__ rng_out) {
 	static_assert(!EXTEND || SCENE_LDS, "the fused extend intersects against the LDS copy of the scene");
-	static_assert(!GEN || (FIRST && EXTEND), "generation is fused into the first shade of an LDS-resident scene only");
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
 	stage_jump31(s_jump);
@@ -510,53 +493,109 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 		for (uint32_t k = threadIdx.x; k < nt4; k += kBlock) s_scene[k] = g_tris[k];
 		for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = g_mats[k];
 		tris = s_scene; mats = s_scene + nt4;
-		if (GEN) stage_primary_records(g_tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_scene + nt4 + nm2);
 	}
-	const float4* s_prim = s_scene + n_tris * 4 + n_mats * 2;
 	__shared__ uint32_t s_out, s_traced;
 	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
 	__syncthreads();
-	ShadeCtx c{ f, tris, mats, s_prim, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, smat, rng_in, &s_out, &s_traced };
-	shade_block<FIRST, EXTEND, GEN, RESOLVE>(c, last_bounce, count_ptr[blockIdx.x], qa, qb, qc, qpid, hit, oa, ob, oc, opid, ohit);
+	ShadeCtx c{ f, tris, mats, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
+	shade_block<FIRST, EXTEND, false>(c, last_bounce, count_ptr[blockIdx.x], qa, qb, qc, qpid, hit, oa, ob, oc, opid, ohit);
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		count_out[blockIdx.x] = s_out;
-		if (RESOLVE) ray_count_out[blockIdx.x] = s_traced;
-	}
+	if (threadIdx.x == 0) count_out[blockIdx.x] = s_out;
 }
 
-// The whole bounce loop of a pass in ONE launch (LDS-resident scene).  Queue slots are owned block by block, so the paths
-// a block queues at bounce b are exactly the ones it shades at bounce b+1: nothing is exchanged between blocks and the
-// reference's per-bounce launches (PathTracer.cu:129-151) need no grid-wide barrier here -- a block barrier between
-// bounces is enough (the waves of a block share the CU's L1, so its own stores are visible to it after __syncthreads).
-// Bounce 0 generates its camera rays (GEN); terminal next hits are resolved by their producer (RESOLVE); the per-bounce
-// counters are still written, for the statistics.
+// pass_mat[0] = step^(frame_first*stride), pass_mat[1] = step^stride (exponents mod 2^32-1): what a pass needs to walk
+// a pixel's strided streams sample by sample.  Two blocks of 32 lanes.
+__global__ void k_pass_matrices(uint32_t frame_first, uint32_t stride, uint32_t* __restrict__ pass_mat) {
+	uint32_t b = threadIdx.x;
+	unsigned long long k = (blockIdx.x == 0 ? (unsigned long long)frame_first * stride : (unsigned long long)stride) % 0xFFFFFFFFull;
+	uint32_t x = 1u << b;
+	for (int j = 0; k; j++, k >>= 1)
+		if (k & 1u) x = mat_apply(g_jump.cols[j], x);
+	pass_mat[32u * blockIdx.x + b] = x;
+}
+
+// A whole pass of an LDS-resident scene in ONE launch: camera rays, the bounce loop, and the fold into the mean.
+//
+// Ownership.  Block b owns the pixel chunks {k : k % G == b} (256 pixels each) with ALL samples of the pass, and, like
+// every stage here, its own slots of the queues.  So the paths a block queues at bounce i are exactly the ones it shades
+// at bounce i+1 and every radiance of a pixel is written by the block that folds it: nothing is exchanged between
+// blocks, the reference's per-bounce launches (PathTracer.cu:129-151) need no grid-wide barrier, a block barrier is
+// enough (the waves of a block share the CU's L1, so its own stores are visible to it after __syncthreads).
+//
+// Bounce 0 (a4..a9 fused): a lane keeps its pixel and walks the pass's samples in order, so the pixel coordinates are
+// divided out once per pixel, not per path, and the strided stream of sample s+1 is ONE byte-table jump (step^stride,
+// 4 LDS lookups) from that of sample s instead of a 32-column matrix product per path; the bounce-0 queue is never
+// materialised.  Terminal next hits are resolved by their producer (RESOLVE).  After the last bounce the block folds
+// its pixels' samples into the running mean in sample order (a10) -- no separate accumulate launch, and the flags and
+// radiances it reads are still in its L1/L2.  The per-bounce counters are still written, for the statistics.
 __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                        float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
                                                        float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
                                                        uint32_t* __restrict__ counts, uint32_t* __restrict__ ray_counts, uint32_t capacity,
                                                        float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out,
-                                                       const uint32_t* __restrict__ smat, const uint32_t* __restrict__ rng_in) {
+                                                       const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
+                                                       uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean) {
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
+	__shared__ uint32_t s_stride[1024];       // STRIDED: byte tables of step^stride
 	__shared__ uint32_t s_out, s_traced;
 	stage_jump31(s_jump);
+	const bool strided = f.rng_mode == PT_RNG_STRIDED;
+	if (strided) {
+		// table[j][v] = step^stride(v << 8j) = xor of the columns 8j+i over the set bits i of v
+		for (uint32_t e = threadIdx.x; e < 1024u; e += kBlock) {
+			uint32_t j = e >> 8, v = e & 255u, x = 0;
+			for (uint32_t i = 0; i < 8; i++) x ^= pass_mat[32u + 8u * j + i] & (0u - ((v >> i) & 1u));
+			s_stride[e] = x;
+		}
+	}
 	const bool det_bounded = scene_det_bounded(scene);
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const float4* g_mats = g_tris + (size_t)n_tris * 4;
 	uint32_t nt4 = n_tris * 4, nm2 = n_mats * 2;
 	for (uint32_t k = threadIdx.x; k < nt4; k += kBlock) s_scene[k] = g_tris[k];
 	for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = g_mats[k];
+	const float4* s_prim = s_scene + nt4 + nm2;
 	stage_primary_records(g_tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_scene + nt4 + nm2);
 	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
 	__syncthreads();
-	ShadeCtx c{ f, s_scene, s_scene + nt4, s_scene + nt4 + nm2, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, smat, rng_in, &s_out, &s_traced };
+	ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
 	const uint32_t G = gridDim.x;
-	uint32_t count = counts[blockIdx.x];                     // bounce 0: this block's share of the identity slots (k_set_count)
-	shade_block<true, true, true, true>(c, f.depth <= 1u ? 1u : 0u, count, nullptr, nullptr, nullptr, nullptr, nullptr, a1, b1, c1, pid1, hit1);
+	const bool extended = f.shading == PT_SHADING_EXTENDED;
+
+	// bounce 0
+	{
+		const uint32_t last = f.depth <= 1u ? 1u : 0u;
+		uint32_t owned = 0;
+		for (uint32_t li0 = blockIdx.x * kBlock; li0 < f.pixel_count; li0 += G * kBlock) {
+			uint32_t li = li0 + threadIdx.x;
+			bool active = li < f.pixel_count;
+			owned += min((uint32_t)kBlock, f.pixel_count - li0);
+			uint32_t i = f.pixel_first + (active ? li : 0u);
+			uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
+			uint32_t r0 = active ? rng_in[li] : 0u;
+			if (strided) r0 = mat_apply(pass_mat, r0);         // start of the pass's first sample
+			for (uint32_t s = 0; s < n_samples; s++) {
+				if (strided && s) r0 = byte_jump(s_stride, r0);
+				PathNext r;
+				r.pid = s * f.pixel_count + li;
+				if (active) {
+					uint32_t rs = r0;                               // r0 stays the start of this sample's stream
+					Vec3 gd = primary_direction(f, px, py, rs);
+					float best = FLT_MAX;
+					uint32_t ptri = kNoHit;
+					intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri);
+					shade_lane<true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
+					                                  float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
+				}
+				queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1);
+			}
+		}
+		if (threadIdx.x == 0) { counts[blockIdx.x] = owned * n_samples; ray_counts[blockIdx.x] = owned * n_samples; }
+	}
 	for (uint32_t b = 1;; b++) {
 		__syncthreads();
-		count = s_out;
+		uint32_t count = s_out;
 		uint32_t traced = s_traced;
 		__syncthreads();
 		if (threadIdx.x == 0) {
@@ -572,8 +611,20 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 			break;
 		}
 		uint32_t last = b + 1 >= f.depth ? 1u : 0u;
-		if (b & 1u) shade_block<false, true, false, true>(c, last, count, a1, b1, c1, pid1, hit1, a0, b0, c0, pid0, hit0);
-		else shade_block<false, true, false, true>(c, last, count, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1);
+		if (b & 1u) shade_block<false, true, true>(c, last, count, a1, b1, c1, pid1, hit1, a0, b0, c0, pid0, hit0);
+		else shade_block<false, true, true>(c, last, count, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1);
+	}
+	// a10: this block's pixels, the pass's samples folded in order
+	__syncthreads();
+	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < f.pixel_count; li += G * kBlock) {
+		float4 m = mean[li];
+		for (uint32_t s = 0; s < n_samples; s++) {
+			size_t p = (size_t)s * f.pixel_count + li;
+			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };        // kernels.cu:49
+			if (lit[p]) frame = radiance[p];
+			m = running_mean(frame, m, mean_first + s);
+		}
+		mean[li] = m;
 	}
 }
 
@@ -766,22 +817,32 @@ struct Workspace {
 	unsigned char* lit;  // 1 byte per path: 1 = radiance[] holds the sample, 0 = the sample is (0,0,0,1)
 	uint32_t* counts;    // (PT_MAX_DEPTH + 2) x G words: per bounce, per queue block
 	uint32_t* ray_counts; // same shape: rays traced per bounce, where terminal hits never enter the queue (k_shade RESOLVE)
-	uint32_t* smat;      // samples_per_pass x 32 words (STRIDED)
+	uint32_t* smat;      // max(samples_per_pass, 2) x 32 words (STRIDED)
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-size_t carve(Workspace* w, unsigned char* base, size_t paths, uint32_t samples_per_pass) {
+// Queue capacity of a pass.  The one-launch pass (k_bounces) gives block b the pixel chunks {k : k % G == b} with all
+// samples, G = grid_for(pixel_count), so every block needs ceil(chunks/G) * samples_per_pass rows of 256 slots: the
+// path count rounded up to whole rows for every block (at most one chunk-row of padding per block).
+size_t queue_capacity(uint32_t pixel_count, uint32_t samples_per_pass) {
+	size_t chunks = ((size_t)pixel_count + kBlock - 1) / kBlock;
+	size_t G = (size_t)grid_for(pixel_count);
+	return G * ((chunks + G - 1) / G) * samples_per_pass * kBlock;
+}
+
+size_t carve(Workspace* w, unsigned char* base, uint32_t pixel_count, uint32_t samples_per_pass) {
 	size_t off = 0;
 	auto take = [&](size_t bytes) { unsigned char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+	size_t paths = (size_t)pixel_count * samples_per_pass, slots = queue_capacity(pixel_count, samples_per_pass);
 	for (int k = 0; k < 2; k++) {
-		w->a[k] = (float4*)take(paths * 16); w->b[k] = (float4*)take(paths * 16); w->c[k] = (float4*)take(paths * 16);
-		w->pid[k] = (uint32_t*)take(paths * 4);
+		w->a[k] = (float4*)take(slots * 16); w->b[k] = (float4*)take(slots * 16); w->c[k] = (float4*)take(slots * 16);
+		w->pid[k] = (uint32_t*)take(slots * 4);
 	}
-	w->hit[0] = (uint2*)take(paths * 8); w->hit[1] = (uint2*)take(paths * 8);
+	w->hit[0] = (uint2*)take(slots * 8); w->hit[1] = (uint2*)take(slots * 8);
 	w->radiance = (float4*)take(paths * 16);
 	w->lit = (unsigned char*)take(paths);
 	w->counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
 	w->ray_counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
-	w->smat = (uint32_t*)take((size_t)samples_per_pass * 32 * 4);
+	w->smat = (uint32_t*)take((size_t)std::max(samples_per_pass, 2u) * 32 * 4);
 	return off;
 }
 
@@ -1058,29 +1119,21 @@ int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob
 	return PT_OK;
 }
 
-// gen_rng != nullptr: bounce 0 generates its camera rays itself (k_shade<..., GEN>); gen_smat = the pass's jump matrices (STRIDED)
 static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneInfo& si, uint32_t bounce,
                         pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
-                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s,
-                        const uint32_t* gen_smat = nullptr, const uint32_t* gen_rng = nullptr, uint32_t* ray_count_out = nullptr) {
+                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s) {
 	uint32_t last = (bounce + 1 >= f.depth) ? 1u : 0u;
 	bool lds = shade_scene_in_lds(si);
 	bool extend = hit_out != nullptr;
 	if (extend && !lds) return fail(PT_ERR_INVALID, "shade: the fused extend needs a scene that fits LDS (<= 1536 triangles, <= 256 materials)");
-	bool gen = gen_rng != nullptr;
-	if (gen && !(bounce == 0 && extend)) return fail(PT_ERR_INVALID, "shade: generation can only be fused into bounce 0 of an LDS-resident scene");
-	size_t lds_bytes = shade_lds_bytes(si) + (gen ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
+	size_t lds_bytes = shade_lds_bytes(si);
 	dim3 grid(grid_for(capacity)), block(kBlock);
-	bool resolve = ray_count_out != nullptr;
-	if (resolve && !extend) return fail(PT_ERR_INVALID, "shade: terminal hits are resolved only with the fused extend");
-#define PT_SHADE(FIRST, LDS, EXT, GEN) if (resolve) PT_SHADE_R(FIRST, LDS, EXT, GEN, (EXT)); else PT_SHADE_R(FIRST, LDS, EXT, GEN, false)
-#define PT_SHADE_R(FIRST, LDS, EXT, GEN, RES) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT, GEN, RES>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
+#define PT_SHADE(FIRST, LDS, EXT) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
 	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
-	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng, gen_smat, gen_rng, ray_count_out)
-	if (bounce == 0) { if (gen) PT_SHADE(true, true, true, true); else if (extend) PT_SHADE(true, true, true, false); else if (lds) PT_SHADE(true, true, false, false); else PT_SHADE(true, false, false, false); }
-	else { if (extend) PT_SHADE(false, true, true, false); else if (lds) PT_SHADE(false, true, false, false); else PT_SHADE(false, false, false, false); }
+	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng)
+	if (bounce == 0) { if (extend) PT_SHADE(true, true, true); else if (lds) PT_SHADE(true, true, false); else PT_SHADE(true, false, false); }
+	else { if (extend) PT_SHADE(false, true, true); else if (lds) PT_SHADE(false, true, false); else PT_SHADE(false, false, false); }
 #undef PT_SHADE
-#undef PT_SHADE_R
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
@@ -1116,7 +1169,7 @@ size_t pt_hip_wavefront_workspace_bytes(uint32_t pixel_count, uint32_t samples_p
 	(void)depth;
 	Workspace w;
 	samples_per_pass = std::max(1u, samples_per_pass);
-	return carve(&w, nullptr, (size_t)pixel_count * samples_per_pass, samples_per_pass);
+	return carve(&w, nullptr, pixel_count, samples_per_pass);
 }
 
 int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
@@ -1129,51 +1182,48 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	if (frame->rng_mode == PT_RNG_SEQUENTIAL) samples_per_pass = 1;
 	if (samples_per_pass == 0) samples_per_pass = 1;
 	samples_per_pass = std::min(samples_per_pass, n_samples);
-	if ((uint64_t)samples_per_pass * frame->pixel_count > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "render_wavefront: more than 2^32-1 paths per pass");
+	if (queue_capacity(frame->pixel_count, samples_per_pass) > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "render_wavefront: more than 2^32-1 queue slots per pass");
 	size_t paths_cap = (size_t)frame->pixel_count * samples_per_pass;
 	Workspace w;
-	if (carve(&w, (unsigned char*)workspace, paths_cap, samples_per_pass) > workspace_bytes) return fail(PT_ERR_NOMEM, "render_wavefront: workspace too small");
+	if (carve(&w, (unsigned char*)workspace, frame->pixel_count, samples_per_pass) > workspace_bytes) return fail(PT_ERR_NOMEM, "render_wavefront: workspace too small");
 	if (((uintptr_t)workspace & 255u) != 0) return fail(PT_ERR_INVALID, "render_wavefront: workspace must be 256-byte aligned");
 	hipStream_t s = (hipStream_t)stream;
 	SceneInfo si{ n_triangles, n_materials };
 	FrameDev f = to_dev(*frame);
 	const bool sequential = frame->rng_mode == PT_RNG_SEQUENTIAL;
-	const uint32_t G = (uint32_t)grid_for(paths_cap);     // queue blocks: fixed for every stage of every pass
-	// scene resident in LDS: extend is fused into generate/shade and there is no separate extend pass
+	// scene resident in LDS: the whole pass is one launch (k_bounces)
 	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si);
+	// queue blocks: fixed for every stage of every pass
+	const uint32_t G = (uint32_t)(fuse ? grid_for(frame->pixel_count) : grid_for(paths_cap));
+	const uint32_t slots = (uint32_t)queue_capacity(frame->pixel_count, samples_per_pass);
 
 	for (uint32_t done = 0; done < n_samples; done += samples_per_pass) {
 		uint32_t ns = std::min(samples_per_pass, n_samples - done);
 		uint32_t paths = ns * frame->pixel_count;
-		hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
-		// LDS-resident scene: no generate pass, the first shade makes its own camera rays, and every shade finishes the
-		// paths whose next hit is terminal (lit flags start at zero, rays are counted apart from the queue)
 		if (fuse) {
-			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.ray_counts, G, paths);
+			// LDS-resident scene: ONE launch per pass -- camera rays, every bounce (paths whose next hit is terminal are
+			// finished by their producer: lit flags start at zero, rays are counted apart from the queue) and the fold
+			// into the mean; queue slots and pixels are block-private, so no stage waits for another block
 			HIP_TRY(hipMemsetAsync(w.lit, 0, paths, s));
-			if (!sequential) hipLaunchKernelGGL(k_sample_matrices, dim3(ns), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
-		} else if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
-		if (fuse) {
-			// one launch for the whole bounce loop: queue slots are block-private, so no stage waits for another block
+			if (!sequential) hipLaunchKernelGGL(k_pass_matrices, dim3(2), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
 			size_t lds_bytes = shade_lds_bytes(si) + (size_t)si.n_tris * sizeof(PrimRec);
 			hipLaunchKernelGGL(k_bounces, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats,
 			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1],
-			                   w.counts, w.ray_counts, (uint32_t)paths_cap, w.radiance, w.lit, sequential ? rng : nullptr,
-			                   (const uint32_t*)w.smat, (const uint32_t*)rng);
-		}
-		for (uint32_t b = 0; !fuse && b < frame->depth; b++) {
-			int in = b & 1, out = in ^ 1;
-			if (!fuse)
+			                   w.counts, w.ray_counts, slots, w.radiance, w.lit, sequential ? rng : nullptr,
+			                   (const uint32_t*)w.smat, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean);
+		} else {
+			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
+			if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
+			for (uint32_t b = 0; b < frame->depth; b++) {
+				int in = b & 1, out = in ^ 1;
 				launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
-			pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
-			if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
-			                          fuse ? w.hit[out] : nullptr, w.counts + (size_t)(b + 1) * G,
-			                          w.radiance, w.lit, sequential ? rng : nullptr, s,
-			                          fuse && b == 0 ? w.smat : nullptr, fuse && b == 0 ? rng : nullptr,
-			                          fuse ? w.ray_counts + (size_t)(b + 1) * G : nullptr)) return rc;
+				pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
+				if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
+				                          nullptr, w.counts + (size_t)(b + 1) * G, w.radiance, w.lit, sequential ? rng : nullptr, s)) return rc;
+			}
+			hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
+			                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
 		}
-		hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
-		                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
 		if (stats) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)(fuse ? w.ray_counts : w.counts), G, frame->depth, (unsigned long long*)stats);
 		HIP_TRY(hipGetLastError());
 	}
