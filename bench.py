@@ -234,7 +234,7 @@ def main():
                        "parallelism": "single GPU" if not dist else f"sample split x{world}, fixed-order combine over RCCL (all_to_all + all_gather), overlapped with the next step"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_fused" if args.engine == "fused" else "wavefront pass (generate+extend+shade+accumulate)",
+                         "kernel": "k_fused" if args.engine == "fused" else "wavefront step: 4 passes of 16 spp, one k_bounces launch each (camera rays + bounce loop + fold)",
                          "kernel_ms": round(last_ms, 4), "algorithmic_bytes_per_ray": round(BYTES_PER_RAY, 2),
                          "rays_per_launch": int(rays_per_launch)},
         }

@@ -20,7 +20,7 @@ for eng in ("fused", "wavefront"):
             if m:
                 agg[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in agg.items():
-            if any(x in k for x in ("k_fused", "k_shade", "k_extend", "k_generate", "k_accumulate")):
+            if any(x in k for x in ("k_fused", "k_shade", "k_extend", "k_generate", "k_accumulate", "k_bounces")):
                 for c, vals in v.items():
                     res.setdefault(eng, {}).setdefault(k, {})[c] = {"mean": sum(vals) / len(vals), "max": max(vals), "n": len(vals)}
 json.dump(res, sys.stdout, indent=1)
