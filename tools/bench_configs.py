@@ -21,15 +21,16 @@ from oracle import pt_oracle_py as po  # noqa: E402
 
 def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pass=16, shading=0):
     V, T, M = scene
+    # strided RNG so that the wavefront engine batches samples; the stride covers the worst case of the shading in use
+    # (reference: 2 + 33 draws per bounce; extended: 2 + 2 per bounce).  The fused engine keeps the reference's own
+    # sequential streams under reference shading.  Each run is checked against the oracle in its own mode.
+    strided = bool(shading) or engine == "wavefront"
+    stride = 2 + (2 if shading else 33) * depth
     with pt.PathTracer(w, h) as tr:
         tr.set_scene(*pt.make_scene(V, T, M))
-        if engine == "wavefront":
-            # strided RNG so that the wavefront engine batches samples; stride covers the worst case of either shading
-            tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT, depth=depth, samples_per_pass=samples_per_pass, shading=shading,
-                           rng_mode=pt.PT_RNG_STRIDED if shading else pt.PT_RNG_SEQUENTIAL, stride=2 + 2 * depth)
-        else:
-            tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth, shading=shading,
-                           rng_mode=pt.PT_RNG_STRIDED if shading else pt.PT_RNG_SEQUENTIAL, stride=2 + 2 * depth)
+        tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT if engine == "wavefront" else pt.PT_ENGINE_FUSED, depth=depth,
+                       samples_per_pass=samples_per_pass, shading=shading,
+                       rng_mode=pt.PT_RNG_STRIDED if strided else pt.PT_RNG_SEQUENTIAL, stride=stride)
         tr.render(1)                    # warm-up (also restarts below)
         tr.set_options(depth=depth)     # restart accumulation
         t0 = time.perf_counter()
@@ -40,10 +41,10 @@ def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pa
     ok = None
     if check_pixels:
         ids = np.unique(np.random.default_rng(3).integers(0, w * h, check_pixels)).astype(np.uint32)
-        ref, _, _, _ = po.render(po.params(w, h, depth=depth, spp=spp, shading=shading, stride=2 + 2 * depth,
-                                           rng_mode=po.RNG_STRIDED if shading else po.RNG_SEQUENTIAL), scene=po.make_scene(V, T, M), pixel_ids=ids)
+        ref, _, _, _ = po.render(po.params(w, h, depth=depth, spp=spp, shading=shading, stride=stride,
+                                           rng_mode=po.RNG_STRIDED if strided else po.RNG_SEQUENTIAL), scene=po.make_scene(V, T, M), pixel_ids=ids)
         ok = bool(np.array_equal(img[ids].view(np.uint32), ref.view(np.uint32)))
-    print(json.dumps({"config": name, "engine": engine, "triangles": len(T), "size": f"{w}x{h}", "spp": spp, "depth": depth,
+    print(json.dumps({"config": name, "engine": engine, "triangles": len(T), "size": f"{w}x{h}", "spp": spp, "depth": depth, "rng": f"strided/{stride}" if strided else "sequential",
                       "rays": int(st.rays), "rays_per_pixel_sample": round(st.rays / (w * h * spp), 3),
                       "device_ms": round(st.total_render_ms, 3), "wall_ms": round(dt * 1e3, 3),
                       "Mrays_per_s": round(st.rays / (st.total_render_ms * 1e-3) / 1e6, 1),
