@@ -94,6 +94,8 @@ def main():
             sc = scenes.synthetic_scene(n)
             for eng in ("fused", "wavefront"):
                 run(f"C4 synthetic {n}", sc, 1920, 1080, 4 if n >= 10000 else 16, 10, eng, check_pixels=300)
+    if "c4_10k" in which:
+        run("C4 synthetic 10000", scenes.synthetic_scene(10000), 1920, 1080, args.spp, 10, "wavefront", check_pixels=100)
     if "c4big" in which:
         for n in (10000, 30000, 100000):
             sc = scenes.synthetic_scene(n)
