@@ -1,0 +1,108 @@
+"""The device code's per-pixel recurrence against the oracle, bit for bit, without a GPU.
+
+tests/host/fused_host_check.cpp compiles pathtracer_amd/csrc/pt_device.hpp with g++ through a stand-in
+hip_runtime.h (one lane, ASan + UBSan) and drives it with a loop that mirrors k_fused.  Everything the kernels
+compute per pixel is the code under test here -- camera rays (IEEE and verified-fast division forms), the
+camera-ray records, brute-force and BVH intersection, both shadings, the running mean, strided stream
+addressing -- only the launch geometry, LDS staging and wave-level scheduling are left to the GPU tests.
+(v_rcp_f32 / v_sqrt_f32 are exact divisions / square roots in the stand-in; that the short forms built on the
+hardware instructions return the same bits is what tests/proofs/exact_rcp_sqrt.hip proves on the GPU.)"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import scenes
+from test_bvh_host import pack
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "tests", "host", "fused_host_check")
+
+
+def run_host(pt, oracle, tmp_path, scene, w, h, spp, depth=10, cam=None, rng_mode=0, stride=35, shading=0, flags=0,
+             frame_first=0, pixel_first=0, pixel_count=None):
+    V, T, M = scene
+    c = oracle.camera_corners(cam or oracle.default_camera(), np.float32(w) / np.float32(h))
+    f4 = lambda v: pt.Float4(v.x, v.y, v.z, v.w)
+    n = w * h - pixel_first if pixel_count is None else pixel_count
+    fr = pt.Frame(width=w, height=h, pixel_first=pixel_first, pixel_count=n, depth=depth, seed=1337, rng_mode=rng_mode, stride=stride,
+                  shading=shading, flags=flags, origin=f4(c[0]), top_left=f4(c[1]), bottom_left=f4(c[2]), bottom_right=f4(c[3]))
+    blob, frame, out = tmp_path / "scene.blob", tmp_path / "frame.bin", tmp_path / "out.bin"
+    blob.write_bytes(pack(pt, V, T, M))
+    frame.write_bytes(bytes(fr))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([CHECK, str(blob), str(frame), str(frame_first), str(frame_first), str(spp), str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    img = raw[:16 * n].view(np.float32).reshape(n, 4)
+    rng = raw[16 * n:].view(np.uint32)
+    rays = int(r.stdout.split()[5])
+    return img, rng, rays
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+needs_binary = pytest.mark.skipif(not os.path.exists(CHECK), reason="tests/host/fused_host_check is not built (__graft_entry__.build())")
+
+
+@needs_binary
+@pytest.mark.parametrize("w,h,spp,flags", [(64, 48, 2, 0), (160, 120, 1, 0), (96, 54, 3, 1)])
+def test_default_scene(pt, oracle, tmp_path, w, h, spp, flags):
+    """flags = 1 (PT_FRAME_FAST_DIV): the multiply + two residual corrections in place of the two IEEE divisions of
+    the ray set-up; on the GPU it is enabled only for sizes pt_hip_verify_fast_div has checked exhaustively."""
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, spp=spp))
+    img, rng, rays = run_host(pt, oracle, tmp_path, scenes.default_scene(), w, h, spp, flags=flags)
+    assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
+
+
+@needs_binary
+def test_all_materials_depth_16_and_moved_camera(pt, oracle, tmp_path):
+    V, T, M = scenes.all_materials_scene()
+    cam = oracle.make_camera(position=(0.1, 0.05, -0.2, 1.0), rotation=(0.05, -0.12, 0.02, 0.99), fov=75.0)
+    w, h, spp = 80, 45, 3
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, cam=cam, depth=16, spp=spp), scene=oracle.make_scene(V, T, M))
+    assert st.rays_per_bounce[3] > 0
+    img, rng, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=16, cam=cam)
+    assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
+
+
+@needs_binary
+@pytest.mark.parametrize("n_tris", [300, 700, 2500])
+def test_synthetic_scenes_brute_force_and_bvh(pt, oracle, tmp_path, n_tris):
+    """300 triangles: the loop over all triangles with the camera-ray records; 700 and 2500: the BVH walk."""
+    V, T, M = scenes.synthetic_scene(n_tris)
+    w, h, spp = 48, 30, 2
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
+    img, rng, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp)
+    assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
+
+
+@needs_binary
+def test_strided_streams_and_a_tile(pt, oracle, tmp_path):
+    """STRIDED addressing from a later sample on (frame_first = 5); the stride (400) differs from what a sample draws, so
+    every sample re-addresses its stream; pixels 1000..2999 only (tile split).  The oracle numbers the running mean from
+    frame_first as well (an image of ones, as the plugin's, weighted 5 : 3 here)."""
+    w, h, spp = 96, 64, 3
+    V, T, M = scenes.all_materials_scene()
+    p = oracle.params(w, h, depth=12, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=400, frame_first=5)
+    ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M), pixel_first=1000, n=2000)
+    img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=12, rng_mode=1, stride=400, frame_first=5, pixel_first=1000, pixel_count=2000)
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+
+
+@needs_binary
+@pytest.mark.parametrize("scene", ["mirror", "synthetic"])
+def test_extended_shading(pt, oracle, tmp_path, scene):
+    V, T, M = scenes.mirror_scene() if scene == "mirror" else scenes.synthetic_scene(1500)
+    if scene == "synthetic":
+        M = [(m[0], m[1], 0.8) for m in M]
+    w, h, spp, depth = 64, 36, 2, 12
+    p = oracle.params(w, h, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=2 + 2 * depth, shading=oracle.SHADING_EXTENDED)
+    ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M))
+    img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, rng_mode=1, stride=2 + 2 * depth, shading=1)
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
