@@ -424,6 +424,60 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack);
 }
 
+constexpr uint32_t kQueueBlock = 256;       // lanes per block == slots per queue row (pt_kernels.hip kBlock)
+
+// The extend stage of one block over its own queue entries, BVH scenes (k_extend<FIRST, true>).
+// Persistent traversal with lane refill: rays differ widely in how many nodes and leaves they visit, so a lane
+// that has finished its ray takes the next one of this block's queue instead of idling until the slowest of its
+// 64 neighbours is done (one LDS counter per block, one add per wave and refill; results are keyed by slot).
+// *s_next is zero (and a block barrier passed) on entry; s_stack is bvh_stack_depth x 256 words of LDS.
+// Every collective below is reached by all 64 lanes of a wave: the loops end on ballots, never per lane
+// (tests/host/extend_wave_check.cpp runs this function as a wave of 64 host threads).
+template <bool FIRST>
+__device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origin, const float4* __restrict__ qa, const float4* __restrict__ qb,
+                                                 uint32_t count, uint32_t capacity, uint2* __restrict__ hit, uint32_t* s_stack, uint32_t* s_next) {
+	const uint32_t G = gridDim.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t* stack = s_stack + threadIdx.x;
+	uint32_t q = 0, tri = kNoHit;
+	float best = 0.0f;
+	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
+	BvhRay r{};
+	int32_t cur = kBvhDone;
+	int sp = 0;
+	bool has_ray = false, exhausted = false;
+	for (;;) {
+		bool idle = cur == kBvhDone;
+		if (idle && has_ray) { hit[q] = uint2{ __float_as_uint(best), tri }; has_ray = false; }
+		unsigned long long idle_mask = __ballot(idle);
+		uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+		// refill when a quarter of the wave idles (the set-up of a ray costs about as much as two node steps)
+		if (!exhausted && (n_idle >= 16u || n_idle == 64u)) {
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(s_next, n_idle);
+			base = __shfl(base, 0, 64);
+			uint32_t j = base + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+			if (base + n_idle >= count) exhausted = true;          // wave-uniform: nothing left after this hand-out
+			if (idle && j < count) {
+				q = ((j / kQueueBlock) * G + blockIdx.x) * kQueueBlock + (j % kQueueBlock);
+				if (q < capacity) {
+					float4 a = float4{ 0, 0, 0, 0 };
+					if (!FIRST) a = qa[q];
+					float4 b = qb[q];
+					o = FIRST ? Vec3{ origin.x, origin.y, origin.z } : Vec3{ a.x, a.y, a.z };
+					d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
+					best = FIRST ? FLT_MAX : b.z;
+					tri = kNoHit;
+					r = bvh_ray_setup(bv, d, best);
+					cur = 0; sp = 0; has_ray = true;
+				}
+			}
+		}
+		if (!__any(cur != kBvhDone)) { if (exhausted) break; else continue; }
+		bvh_round(bv, r, o, d, best, tri, cur, sp, stack);
+	}
+}
+
 // GetDiffuseReflection, Functions.cuh:91-109: rounds of 3 draws (x, y, z in that order) until
 // ((x^2+y^2)+z^2)+1 <= 1 or 11 rounds are done; the last round's sample is used.  w = -1 makes
 // the squared length 1 + |v|^2, so an early end needs every |2u-1| < 2.5e-4 in one round, and an

@@ -33,6 +33,7 @@ using namespace ptd;
 namespace {
 
 constexpr int kBlock = 256;
+static_assert(kBlock == (int)kQueueBlock, "pt_device.hpp lays the traversal stack and the queue rows out for 256-lane blocks");
 constexpr uint32_t kLdsTriChunk = 1024;                 // 64 KiB of packed triangles per stage
 constexpr uint32_t kShadeLdsMaxTris = 1536;             // shade keeps triangles + materials in LDS up to here
 constexpr uint32_t kShadeLdsMaxMats = 256;
@@ -236,51 +237,10 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 		__syncthreads();
 	}
 	if (BVH) {
-		// Persistent traversal with lane refill: rays differ widely in how many nodes and leaves they visit, so a lane
-		// that has finished its ray takes the next one of this block's queue instead of idling until the slowest of its
-		// 64 neighbours is done (one LDS counter per block, one add per wave and refill; results are keyed by slot).
 		__shared__ uint32_t s_next;
 		if (threadIdx.x == 0) s_next = 0;
 		__syncthreads();
-		const uint32_t lane = threadIdx.x & 63u;
-		uint32_t* stack = s_stack + threadIdx.x;
-		uint32_t q = 0, tri = kNoHit;
-		float best = 0.0f;
-		Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
-		BvhRay r{};
-		int32_t cur = kBvhDone;
-		int sp = 0;
-		bool has_ray = false, exhausted = false;
-		for (;;) {
-			bool idle = cur == kBvhDone;
-			if (idle && has_ray) { hit[q] = uint2{ __float_as_uint(best), tri }; has_ray = false; }
-			unsigned long long idle_mask = __ballot(idle);
-			uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-			// refill when a quarter of the wave idles (the set-up of a ray costs about as much as two node steps)
-			if (!exhausted && (n_idle >= 16u || n_idle == 64u)) {
-				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd(&s_next, n_idle);
-				base = __shfl(base, 0, 64);
-				uint32_t j = base + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-				if (base + n_idle >= count) exhausted = true;          // wave-uniform: nothing left after this hand-out
-				if (idle && j < count) {
-					q = ((j / kBlock) * G + blockIdx.x) * kBlock + (j % kBlock);
-					if (q < capacity) {
-						float4 a = float4{ 0, 0, 0, 0 };
-						if (!FIRST) a = qa[q];
-						float4 b = qb[q];
-						o = FIRST ? Vec3{ origin.x, origin.y, origin.z } : Vec3{ a.x, a.y, a.z };
-						d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
-						best = FIRST ? FLT_MAX : b.z;
-						tri = kNoHit;
-						r = bvh_ray_setup(bv, d, best);
-						cur = 0; sp = 0; has_ray = true;
-					}
-				}
-			}
-			if (!__any(cur != kBvhDone)) { if (exhausted) break; else continue; }
-			bvh_round(bv, r, o, d, best, tri, cur, sp, stack);
-		}
+		extend_bvh_block<FIRST>(bv, origin, qa, qb, count, capacity, hit, s_stack, &s_next);
 		return;
 	}
 	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {

@@ -1,10 +1,14 @@
 // Host stand-in for <hip/hip_runtime.h>: just enough to compile pathtracer_amd/csrc/pt_device.hpp with g++ and run its
-// device functions as ONE lane on the CPU (tests/host/bvh_host_check.cpp).  Wave-level builtins see a wave of one lane.
-// Test infrastructure only; nothing in the product includes this.
+// device functions on the CPU -- as ONE lane (the default: wave-level builtins see a wave of one), or as a wave of up to
+// 64 lanes, one host thread each, when a WaveShim is installed (tests/host/extend_wave_check.cpp): every collective
+// (__ballot, __any, __shfl, __syncthreads) is then a rendezvous of all lanes, which is exact for code whose collectives
+// sit in wave-uniform control flow.  Test infrastructure only; nothing in the product includes this.
 #pragma once
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 
 #define __host__
 #define __device__
@@ -18,21 +22,59 @@ struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 struct uint2 { uint32_t x, y; };
 struct Dim3Shim { unsigned x = 0, y = 0, z = 0; };
-static Dim3Shim threadIdx, blockIdx;
+static thread_local Dim3Shim threadIdx;
+static Dim3Shim blockIdx;
 static Dim3Shim blockDim{ 256, 1, 1 }, gridDim{ 1, 1, 1 };
+
+struct WaveShim {
+	int lanes = 1;
+	std::mutex m;
+	std::condition_variable cv;
+	int arrived = 0;
+	unsigned long long generation = 0;
+	unsigned long long slot[2][64];
+	void barrier() {
+		std::unique_lock<std::mutex> lk(m);
+		unsigned long long g = generation;
+		if (++arrived == lanes) { arrived = 0; generation++; cv.notify_all(); }
+		else cv.wait(lk, [&] { return generation != g; });
+	}
+};
+static WaveShim* g_wave = nullptr;
+static thread_local unsigned t_phase = 0;
+
+// every lane contributes v; afterwards out[i] is lane i's value (double-buffered: one rendezvous per collective)
+static inline void wave_exchange(unsigned long long v, unsigned long long* out) {
+	WaveShim* w = g_wave;
+	unsigned ph = t_phase++ & 1u;
+	w->slot[ph][threadIdx.x & 63u] = v;
+	w->barrier();
+	for (int i = 0; i < w->lanes; i++) out[i] = w->slot[ph][i];
+}
 
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
-static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+static inline unsigned long long __ballot(bool p) {
+	if (!g_wave) return p ? 1ull : 0ull;
+	unsigned long long all[64], mask = 0;
+	wave_exchange(p ? 1ull : 0ull, all);
+	for (int i = 0; i < g_wave->lanes; i++) mask |= all[i] << i;
+	return mask;
+}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
-static inline bool __any(bool p) { return p; }
-template <typename T> static inline T __shfl(T v, int, int = 64) { return v; }
-static inline void __syncthreads() {}
+static inline bool __any(bool p) { return __ballot(p) != 0ull; }
+template <typename T> static inline T __shfl(T v, int src, int = 64) {
+	if (!g_wave) return v;
+	static_assert(sizeof(T) <= 8, "shim shuffles up to 64 bits");
+	unsigned long long bits = 0, all[64];
+	std::memcpy(&bits, &v, sizeof(T));
+	wave_exchange(bits, all);
+	T r;
+	std::memcpy(&r, &all[src], sizeof(T));
+	return r;
+}
+static inline void __syncthreads() { if (g_wave) g_wave->barrier(); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }
-template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
-
-
-
-
+template <typename T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

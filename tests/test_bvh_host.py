@@ -6,7 +6,8 @@ reference's loop over all triangles (kernels.cu:62-68) and the BVH walk.  The sc
 the library (pt_hip_scene_pack, host code), the rays are camera rays, rays leaving the walls in random
 directions -- a third of them grazing the wall they start on, where the fp32 Moeller-Trumbore test is
 least accurate and the culling margins of pt_bvh.hpp matter -- with fresh and stale hit distances.
-What a one-lane run cannot show (the wave-level scheduling of k_extend) is covered by the GPU tests."""
+The wave-level side -- the persistent loop of k_extend<*, BVH> with its ballots, lane refill and the quorum rule of
+the node walk -- runs as 64 host threads, one per lane (tests/host/extend_wave_check.cpp)."""
 import ctypes as C
 import os
 import subprocess
@@ -18,6 +19,7 @@ import scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHECK = os.path.join(ROOT, "tests", "host", "bvh_host_check")
+WAVE_CHECK = os.path.join(ROOT, "tests", "host", "extend_wave_check")
 FLT_MAX = np.finfo(np.float32).max
 
 
@@ -84,6 +86,25 @@ def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, cam
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     env.pop("LD_PRELOAD", None)          # ASan must come first in the library list of its own process
     r = subprocess.run([CHECK, str(blob), str(rays)] + [str(c) for c in camera], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fields = r.stdout.split()
+    assert int(fields[1]) == n_rays and int(fields[3]) > n_rays // 3 and int(fields[5]) == 0, r.stdout
+
+
+@pytest.mark.parametrize("name,n_rays,lanes", [("synthetic-1500", 2500, 64), ("synthetic-10000", 700, 64), ("mixed", 1500, 64), ("synthetic-700", 333, 37)])
+def test_extend_stage_as_a_wave_of_host_threads(pt, tmp_path, name, n_rays, lanes):
+    """extend_bvh_block (what k_extend<false, true> runs) with diverging rays: every queue slot gets the brute-force hit.
+    37 lanes: a partial wave, a ray count that is no multiple of it."""
+    if not os.path.exists(WAVE_CHECK):
+        pytest.skip("tests/host/extend_wave_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    V, T, M = mixed_scene() if name == "mixed" else scenes.synthetic_scene(int(name.split("-")[1]))
+    blob, rays = tmp_path / "scene.blob", tmp_path / "rays.f32"
+    blob.write_bytes(pack(pt, V, T, M))
+    camera = (0.2, -0.1, 0.05)
+    make_rays(n_rays, 11, camera).tofile(rays)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([WAVE_CHECK, str(blob), str(rays)] + [str(c) for c in camera] + [str(lanes)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     fields = r.stdout.split()
     assert int(fields[1]) == n_rays and int(fields[3]) > n_rays // 3 and int(fields[5]) == 0, r.stdout
