@@ -24,6 +24,7 @@
 
 #include "pt_hip.h"
 #include "pt_device.hpp"
+#include "pt_wavefront.hpp"
 #include "pt_bvh.hpp"
 
 #pragma clang fp contract(off)
@@ -196,17 +197,6 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev f, const uint32_t*
 	}
 }
 
-// Queue geometry.  A queue of `capacity` slots is owned block by block: block b of the G-block
-// grid owns slots ((r*G + b)*256 + t), r = 0,1,..; its entries are dense in its own index
-// j = r*256 + t.  Each block compacts its survivors into its own slots of the other queue and
-// keeps its own counter, so no stage issues a global atomic (a single counter word saturates at
-// ~88 atomics/us on MI355X -- measured 2.97 ms per 16.6 M-path pass before this layout) and the
-// interleave keeps the blocks' loads statistically equal.  Entry q of the identity queue that
-// generate writes belongs to block (q/256) % G at index (q / (256*G))*256 + q % 256.
-__device__ __forceinline__ uint32_t queue_slot(uint32_t j0, uint32_t G) {   // j0 multiple of 256; add threadIdx.x
-	return ((j0 / kBlock) * G + blockIdx.x) * kBlock;
-}
-
 // counts[0][b]: how many of the first `paths` identity slots block b owns
 __global__ void k_set_count(uint32_t* __restrict__ counts, uint32_t G, uint32_t paths) {
 	uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,165 +257,6 @@ __global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera,
 	}
 }
 
-// a7+a8+a9.  FIRST: bounce 0 (pid = slot, throughput (1,1,1,1) implied, no c/pid reads).
-// Path state is loaded only by the lanes that need it: a miss reads nothing but its hit (and its
-// rng word when the streams are written back), an emitter hit adds the throughput, only a diffuse
-// hit reads the ray.  EXTEND (scene in LDS): the new ray is intersected at once (a5+a6 fused into
-// the producer) and the hit stored with the continuing path, so no extend pass re-reads it.
-// What one block's shade of one bounce needs besides its queues.
-struct ShadeCtx {
-	const FrameDev& f;
-	const float4* tris; const float4* mats; const uint32_t* s_jump;
-	uint32_t n_tris; bool det_bounded; uint32_t capacity;
-	float4* radiance; unsigned char* lit; uint32_t* rng_out;
-	uint32_t* s_out; uint32_t* s_traced;       // LDS counters, zeroed (and a barrier passed) before the call
-};
-
-// What a lane hands to the compaction: the path as the next bounce will read it.
-struct PathNext {
-	bool cont = false, traced = false;
-	float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
-	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
-	float t = 0.0f;
-	uint32_t rng = 0, pid = 0, next_tri = kNoHit;
-};
-
-// One lane, one path: the hit h of slot q is shaded (kernels.cu:44-96).  GEN: the camera ray was made by the caller
-// (gen_b = direction + rng word) and no queue is read.  RESOLVE (needs EXTEND): the continuing ray's hit is known right
-// here, so a path whose next hit is terminal -- nothing, an emitter, or (REFERENCE shading) an absorber -- is finished by
-// its producer and never enters the queue; `lit` must then be zero when the pass starts (a finished path writes only if
-// it reached an emitter).
-template <bool FIRST, bool EXTEND, bool GEN, bool RESOLVE>
-__device__ __forceinline__ void shade_lane(const ShadeCtx& c, bool extended, uint32_t last_bounce, uint32_t q, uint2 h, float4 gen_b,
-                                           const float4* __restrict__ qa, const float4* __restrict__ qb, const float4* __restrict__ qc,
-                                           PathNext& r) {
-	float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };      // kernels.cu:49
-	uint32_t type = 0xFFFFFFFFu;
-	float4 color = float4{ 0, 0, 0, 0 };
-	float reflectivity = 0.0f;
-	Vec3 n{ 0, 0, 0 };
-	if (h.y != kNoHit) {
-		float4 r2 = c.tris[4 * h.y + 2], r3 = c.tris[4 * h.y + 3];
-		uint32_t m = __float_as_uint(r3.x);
-		float4 head = c.mats[2 * m];
-		type = __float_as_uint(head.x);
-		reflectivity = head.y;
-		color = c.mats[2 * m + 1];
-		n = Vec3{ r2.y, r2.z, r2.w };
-	}
-	bool emitted = false;
-	// REFERENCE: only DIFFUSE continues (kernels.cu:79-93); EXTENDED: every hit that is not an emitter does
-	if (type == PT_MAT_DIFFUSE || (extended && h.y != kNoHit && type != PT_MAT_EMISSIVE)) {
-		float4 b = GEN ? gen_b : qb[q];
-		if (FIRST) {
-			r.o = Vec3{ c.f.origin.x, c.f.origin.y, c.f.origin.z }; r.d = Vec3{ b.x, b.y, b.z };
-		} else {
-			float4 a = qa[q];
-			r.step = qc[q];
-			r.o = Vec3{ a.x, a.y, a.z }; r.d = Vec3{ a.w, b.x, b.y };
-		}
-		r.t = __uint_as_float(h.x);
-		r.rng = __float_as_uint(b.w);
-		if (extended) { shade_extended(type, n, color, reflectivity, r.t, r.o, r.d, r.step, r.rng); r.t = FLT_MAX; }   // the next bounce finds its own closest hit
-		else shade_diffuse(n, color, r.t, c.s_jump, r.o, r.d, r.step, r.rng);
-		r.cont = true;
-		if (EXTEND && !last_bounce) intersect_range(c.tris, 0, c.n_tris, c.det_bounded, r.o, r.d, r.t, r.next_tri);
-		if (RESOLVE) {
-			r.traced = !last_bounce;
-			r.cont = false;
-			if (!last_bounce && r.next_tri != kNoHit) {
-				uint32_t m2 = __float_as_uint(c.tris[4 * r.next_tri + 3].x);
-				uint32_t type2 = __float_as_uint(c.mats[2 * m2].x);
-				if (type2 == PT_MAT_EMISSIVE) {
-					float4 c2 = c.mats[2 * m2 + 1];
-					frame = float4{ r.step.x * c2.x, r.step.y * c2.y, r.step.z * c2.z, r.step.w * c2.w };     // :89, as the next shade would
-					emitted = true;
-				} else if (extended || type2 == PT_MAT_DIFFUSE) r.cont = true;
-				// REFERENCE, REFLECTIVE or unknown type: absorbed at the next bounce (:91-93), frame stays (0,0,0,1)
-			}
-		}
-	} else {
-		if (type == PT_MAT_EMISSIVE) {
-			if (!FIRST) r.step = qc[q];
-			frame = float4{ r.step.x * color.x, r.step.y * color.y, r.step.z * color.z, r.step.w * color.w };  // :89
-			emitted = true;
-		}
-		// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
-		if (c.rng_out) r.rng = __float_as_uint(GEN ? gen_b.w : qb[q].w);
-	}
-	if (!r.cont || last_bounce) {
-		// every path that ends sets its flag; only emitter hits carry a radiance, all others are (0,0,0,1)
-		if (!RESOLVE || emitted) c.lit[r.pid] = emitted ? 1 : 0;
-		if (emitted) c.radiance[r.pid] = frame;
-		if (c.rng_out) c.rng_out[r.pid] = r.rng;        // SEQUENTIAL: one sample per pass, pid = local pixel
-	}
-}
-
-// wave64 compaction of the continuing paths into this block's own slots of the output queue: ballot + prefix, one LDS
-// add per wave.  Every lane of the wave calls it.
-template <bool EXTEND, bool RESOLVE>
-__device__ __forceinline__ void queue_push(const ShadeCtx& c, uint32_t last_bounce, const PathNext& r,
-                                           float4* __restrict__ oa, float4* __restrict__ ob, float4* __restrict__ oc,
-                                           uint32_t* __restrict__ opid, uint2* __restrict__ ohit) {
-	const uint32_t lane = threadIdx.x & 63u;
-	if (RESOLVE) {
-		uint32_t n_traced = (uint32_t)__popcll(__ballot(r.traced));
-		if (n_traced && lane == 0) atomicAdd(c.s_traced, n_traced);
-	}
-	unsigned long long mask = __ballot(r.cont);
-	uint32_t n_cont = (uint32_t)__popcll(mask);
-	if (n_cont) {
-		uint32_t wave_base = 0;
-		if (lane == 0) wave_base = atomicAdd(c.s_out, n_cont);
-		wave_base = __shfl(wave_base, 0, 64);
-		if (r.cont && !last_bounce) {
-			uint32_t j = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-			uint32_t pos = ((j / kBlock) * gridDim.x + blockIdx.x) * kBlock + (j % kBlock);
-			oa[pos] = float4{ r.o.x, r.o.y, r.o.z, r.d.x };
-			ob[pos] = float4{ r.d.y, r.d.z, r.t, __uint_as_float(r.rng) };
-			oc[pos] = r.step;
-			opid[pos] = r.pid;
-			if (EXTEND) ohit[pos] = uint2{ __float_as_uint(r.t), r.next_tri };
-		}
-	}
-}
-
-// One bounce of one block: shades the `count` entries of its input queue, compacts the paths that go on into its own
-// slots of the output queue; *c.s_out / *c.s_traced hold the counts afterwards (no barrier at the end).
-template <bool FIRST, bool EXTEND, bool RESOLVE>
-__device__ __forceinline__ void shade_block(const ShadeCtx& c, uint32_t last_bounce, uint32_t count,
-                                            const float4* __restrict__ qa, const float4* __restrict__ qb,
-                                            const float4* __restrict__ qc, const uint32_t* __restrict__ qpid,
-                                            const uint2* __restrict__ hit,
-                                            float4* __restrict__ oa, float4* __restrict__ ob,
-                                            float4* __restrict__ oc, uint32_t* __restrict__ opid,
-                                            uint2* __restrict__ ohit) {
-	const uint32_t G = gridDim.x;
-	const bool extended = c.f.shading == PT_SHADING_EXTENDED;
-	// the entry's hit (and path id) for the NEXT trip are requested before this trip's work: one trip is a chain of
-	// dependent loads otherwise, and at bounce >= 1 most lanes only set a flag, so the kernel ran at a quarter of the HBM rate
-	uint2 h_next = uint2{ 0u, kNoHit };
-	uint32_t pid_next = 0;
-	if (count > 0) {
-		uint32_t q0 = queue_slot(0, G) + threadIdx.x;
-		if (threadIdx.x < count && q0 < c.capacity) { h_next = hit[q0]; if (!FIRST) pid_next = qpid[q0]; }
-	}
-	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
-		uint32_t q = queue_slot(j0, G) + threadIdx.x;
-		bool active = j0 + threadIdx.x < count && q < c.capacity;
-		uint2 h_cur = h_next;
-		uint32_t pid_cur = pid_next;
-		if (j0 + kBlock < count) {
-			uint32_t qn = queue_slot(j0 + kBlock, G) + threadIdx.x;
-			if (j0 + kBlock + threadIdx.x < count && qn < c.capacity) { h_next = hit[qn]; if (!FIRST) pid_next = qpid[qn]; }
-		}
-		PathNext r;
-		r.pid = FIRST ? q : pid_cur;
-		if (active) shade_lane<FIRST, EXTEND, false, RESOLVE>(c, extended, last_bounce, q, h_cur, float4{ 0, 0, 0, 0 }, qa, qb, qc, r);
-		queue_push<EXTEND, RESOLVE>(c, last_bounce, r, oa, ob, oc, opid, ohit);
-	}
-}
-
 template <bool FIRST, bool SCENE_LDS, bool EXTEND>
 __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
@@ -474,20 +305,7 @@ __global__ void k_pass_matrices(uint32_t frame_first, uint32_t stride, uint32_t*
 	pass_mat[32u * blockIdx.x + b] = x;
 }
 
-// A whole pass of an LDS-resident scene in ONE launch: camera rays, the bounce loop, and the fold into the mean.
-//
-// Ownership.  Block b owns the pixel chunks {k : k % G == b} (256 pixels each) with ALL samples of the pass, and, like
-// every stage here, its own slots of the queues.  So the paths a block queues at bounce i are exactly the ones it shades
-// at bounce i+1 and every radiance of a pixel is written by the block that folds it: nothing is exchanged between
-// blocks, the reference's per-bounce launches (PathTracer.cu:129-151) need no grid-wide barrier, a block barrier is
-// enough (the waves of a block share the CU's L1, so its own stores are visible to it after __syncthreads).
-//
-// Bounce 0 (a4..a9 fused): a lane keeps its pixel and walks the pass's samples in order, so the pixel coordinates are
-// divided out once per pixel, not per path, and the strided stream of sample s+1 is ONE byte-table jump (step^stride,
-// 4 LDS lookups) from that of sample s instead of a 32-column matrix product per path; the bounce-0 queue is never
-// materialised.  Terminal next hits are resolved by their producer (RESOLVE).  After the last bounce the block folds
-// its pixels' samples into the running mean in sample order (a10) -- no separate accumulate launch, and the flags and
-// radiances it reads are still in its L1/L2.  The per-bounce counters are still written, for the statistics.
+// One pass of an LDS-resident scene in ONE launch: stages the block's LDS, then bounces_block (pt_wavefront.hpp).
 __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                        float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
                                                        float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
@@ -501,14 +319,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	__shared__ uint32_t s_out, s_traced;
 	stage_jump31(s_jump);
 	const bool strided = f.rng_mode == PT_RNG_STRIDED;
-	if (strided) {
-		// table[j][v] = step^stride(v << 8j) = xor of the columns 8j+i over the set bits i of v
-		for (uint32_t e = threadIdx.x; e < 1024u; e += kBlock) {
-			uint32_t j = e >> 8, v = e & 255u, x = 0;
-			for (uint32_t i = 0; i < 8; i++) x ^= pass_mat[32u + 8u * j + i] & (0u - ((v >> i) & 1u));
-			s_stride[e] = x;
-		}
-	}
+	if (strided) build_stride_table(pass_mat + 32, s_stride);
 	const bool det_bounded = scene_det_bounded(scene);
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const float4* g_mats = g_tris + (size_t)n_tris * 4;
@@ -520,72 +331,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
 	__syncthreads();
 	ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
-	const uint32_t G = gridDim.x;
-	const bool extended = f.shading == PT_SHADING_EXTENDED;
-
-	// bounce 0
-	{
-		const uint32_t last = f.depth <= 1u ? 1u : 0u;
-		uint32_t owned = 0;
-		for (uint32_t li0 = blockIdx.x * kBlock; li0 < f.pixel_count; li0 += G * kBlock) {
-			uint32_t li = li0 + threadIdx.x;
-			bool active = li < f.pixel_count;
-			owned += min((uint32_t)kBlock, f.pixel_count - li0);
-			uint32_t i = f.pixel_first + (active ? li : 0u);
-			uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
-			uint32_t r0 = active ? rng_in[li] : 0u;
-			if (strided) r0 = mat_apply(pass_mat, r0);         // start of the pass's first sample
-			for (uint32_t s = 0; s < n_samples; s++) {
-				if (strided && s) r0 = byte_jump(s_stride, r0);
-				PathNext r;
-				r.pid = s * f.pixel_count + li;
-				if (active) {
-					uint32_t rs = r0;                               // r0 stays the start of this sample's stream
-					Vec3 gd = primary_direction(f, px, py, rs);
-					float best = FLT_MAX;
-					uint32_t ptri = kNoHit;
-					intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri);
-					shade_lane<true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
-					                                  float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
-				}
-				queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1);
-			}
-		}
-		if (threadIdx.x == 0) { counts[blockIdx.x] = owned * n_samples; ray_counts[blockIdx.x] = owned * n_samples; }
-	}
-	for (uint32_t b = 1;; b++) {
-		__syncthreads();
-		uint32_t count = s_out;
-		uint32_t traced = s_traced;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			counts[(size_t)b * G + blockIdx.x] = count;
-			ray_counts[(size_t)b * G + blockIdx.x] = traced;
-			s_out = 0; s_traced = 0;
-		}
-		__syncthreads();
-		if (b >= f.depth) break;
-		if (count == 0) {                                       // nothing left: the remaining rows are zero
-			if (threadIdx.x == 0)
-				for (uint32_t r = b + 1; r <= f.depth; r++) { counts[(size_t)r * G + blockIdx.x] = 0; ray_counts[(size_t)r * G + blockIdx.x] = 0; }
-			break;
-		}
-		uint32_t last = b + 1 >= f.depth ? 1u : 0u;
-		if (b & 1u) shade_block<false, true, true>(c, last, count, a1, b1, c1, pid1, hit1, a0, b0, c0, pid0, hit0);
-		else shade_block<false, true, true>(c, last, count, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1);
-	}
-	// a10: this block's pixels, the pass's samples folded in order
-	__syncthreads();
-	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < f.pixel_count; li += G * kBlock) {
-		float4 m = mean[li];
-		for (uint32_t s = 0; s < n_samples; s++) {
-			size_t p = (size_t)s * f.pixel_count + li;
-			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };        // kernels.cu:49
-			if (lit[p]) frame = radiance[p];
-			m = running_mean(frame, m, mean_first + s);
-		}
-		mean[li] = m;
-	}
+	bounces_block(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, counts, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean);
 }
 
 // a10. One thread per pixel, the pass's samples folded in order.

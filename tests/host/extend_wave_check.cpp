@@ -51,15 +51,14 @@ int main(int argc, char** argv) {
 	uint32_t s_next = 0;
 	WaveShim wave;
 	wave.lanes = lanes;
-	g_wave = &wave;
 	std::vector<std::thread> th;
 	for (int l = 0; l < lanes; l++)
 		th.emplace_back([&, l] {
 			threadIdx.x = (unsigned)l;
+			t_wave = &wave;
 			extend_bvh_block<false>(bv, camera, qa.data(), qb.data(), count, count, hit.data(), s_stack.data(), &s_next);
 		});
 	for (auto& t : th) t.join();
-	g_wave = nullptr;
 	size_t bad = 0, hits = 0;
 	for (uint32_t k = 0; k < count; k++) {
 		const float* r = rays + 7 * k;

@@ -1,8 +1,9 @@
 // Host stand-in for <hip/hip_runtime.h>: just enough to compile pathtracer_amd/csrc/pt_device.hpp with g++ and run its
-// device functions on the CPU -- as ONE lane (the default: wave-level builtins see a wave of one), or as a wave of up to
-// 64 lanes, one host thread each, when a WaveShim is installed (tests/host/extend_wave_check.cpp): every collective
-// (__ballot, __any, __shfl, __syncthreads) is then a rendezvous of all lanes, which is exact for code whose collectives
-// sit in wave-uniform control flow.  Test infrastructure only; nothing in the product includes this.
+// device functions on the CPU -- as ONE lane (the default: wave-level builtins see a wave of one), or as waves of up to
+// 64 lanes in a block, one host thread per lane, when the thread has a WaveShim installed (t_wave; t_block for the
+// block barrier: tests/host/extend_wave_check.cpp, bounces_block_check.cpp): every collective (__ballot, __any,
+// __shfl, __syncthreads) is then a rendezvous of all its lanes, which is exact for code whose collectives sit in
+// wave-uniform (block-uniform) control flow.  Test infrastructure only; nothing in the product includes this.
 #pragma once
 #include <cmath>
 #include <condition_variable>
@@ -40,12 +41,13 @@ struct WaveShim {
 		else cv.wait(lk, [&] { return generation != g; });
 	}
 };
-static WaveShim* g_wave = nullptr;
+static thread_local WaveShim* t_wave = nullptr;      // this lane's wave; null: a wave of one lane
+static thread_local WaveShim* t_block = nullptr;     // every lane of the block (__syncthreads); null: the wave itself
 static thread_local unsigned t_phase = 0;
 
 // every lane contributes v; afterwards out[i] is lane i's value (double-buffered: one rendezvous per collective)
 static inline void wave_exchange(unsigned long long v, unsigned long long* out) {
-	WaveShim* w = g_wave;
+	WaveShim* w = t_wave;
 	unsigned ph = t_phase++ & 1u;
 	w->slot[ph][threadIdx.x & 63u] = v;
 	w->barrier();
@@ -55,16 +57,16 @@ static inline void wave_exchange(unsigned long long v, unsigned long long* out) 
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline unsigned long long __ballot(bool p) {
-	if (!g_wave) return p ? 1ull : 0ull;
+	if (!t_wave) return p ? 1ull : 0ull;
 	unsigned long long all[64], mask = 0;
 	wave_exchange(p ? 1ull : 0ull, all);
-	for (int i = 0; i < g_wave->lanes; i++) mask |= all[i] << i;
+	for (int i = 0; i < t_wave->lanes; i++) mask |= all[i] << i;
 	return mask;
 }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline bool __any(bool p) { return __ballot(p) != 0ull; }
 template <typename T> static inline T __shfl(T v, int src, int = 64) {
-	if (!g_wave) return v;
+	if (!t_wave) return v;
 	static_assert(sizeof(T) <= 8, "shim shuffles up to 64 bits");
 	unsigned long long bits = 0, all[64];
 	std::memcpy(&bits, &v, sizeof(T));
@@ -73,7 +75,9 @@ template <typename T> static inline T __shfl(T v, int src, int = 64) {
 	std::memcpy(&r, &all[src], sizeof(T));
 	return r;
 }
-static inline void __syncthreads() { if (g_wave) g_wave->barrier(); }
+static inline void __syncthreads() { if (t_block) t_block->barrier(); else if (t_wave) t_wave->barrier(); }
+static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }

@@ -19,10 +19,12 @@ from test_bvh_host import pack
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHECK = os.path.join(ROOT, "tests", "host", "fused_host_check")
+BLOCK_CHECK = os.path.join(ROOT, "tests", "host", "bounces_block_check")
 
 
 def run_host(pt, oracle, tmp_path, scene, w, h, spp, depth=10, cam=None, rng_mode=0, stride=35, shading=0, flags=0,
-             frame_first=0, pixel_first=0, pixel_count=None):
+             frame_first=0, pixel_first=0, pixel_count=None, wavefront=None):
+    """wavefront = (samples_per_pass, max_blocks): the one-launch wavefront pass, block by block, instead of the fused loop"""
     V, T, M = scene
     c = oracle.camera_corners(cam or oracle.default_camera(), np.float32(w) / np.float32(h))
     f4 = lambda v: pt.Float4(v.x, v.y, v.z, v.w)
@@ -34,7 +36,11 @@ def run_host(pt, oracle, tmp_path, scene, w, h, spp, depth=10, cam=None, rng_mod
     frame.write_bytes(bytes(fr))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     env.pop("LD_PRELOAD", None)
-    r = subprocess.run([CHECK, str(blob), str(frame), str(frame_first), str(frame_first), str(spp), str(out)], capture_output=True, text=True, env=env, timeout=600)
+    if wavefront:
+        cmd = [BLOCK_CHECK, str(blob), str(frame), str(frame_first), str(spp), str(wavefront[0]), str(wavefront[1]), str(out)]
+    else:
+        cmd = [CHECK, str(blob), str(frame), str(frame_first), str(frame_first), str(spp), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = np.fromfile(out, dtype=np.uint8)
     img = raw[:16 * n].view(np.float32).reshape(n, 4)
@@ -105,4 +111,47 @@ def test_extended_shading(pt, oracle, tmp_path, scene):
     p = oracle.params(w, h, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=2 + 2 * depth, shading=oracle.SHADING_EXTENDED)
     ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M))
     img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, rng_mode=1, stride=2 + 2 * depth, shading=1)
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+
+
+# ---- the wavefront engine's one-launch pass (pt_wavefront.hpp, bounces_block) as blocks of 256 host threads ----
+needs_block_binary = pytest.mark.skipif(not os.path.exists(BLOCK_CHECK), reason="tests/host/bounces_block_check is not built (__graft_entry__.build())")
+
+
+@needs_block_binary
+@pytest.mark.parametrize("w,h,spp,per_pass,max_blocks", [(64, 40, 3, 1, 64), (75, 41, 5, 2, 4), (128, 72, 6, 4, 3)])
+def test_wavefront_pass_default_scene(pt, oracle, tmp_path, w, h, spp, per_pass, max_blocks):
+    """75 x 41 = 3075 pixels: a ragged last chunk; 4 and 3 blocks: every block owns several chunks; 6 samples in passes
+    of 4: a short last pass.  Strided streams (stride 35 = the default scene's own draw count) and, with one sample per
+    pass, the reference's sequential streams."""
+    mode = dict(rng_mode=oracle.RNG_SEQUENTIAL) if per_pass == 1 else dict(rng_mode=oracle.RNG_STRIDED, stride=35)
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, spp=spp, **mode))
+    img, rng, rays = run_host(pt, oracle, tmp_path, scenes.default_scene(), w, h, spp, rng_mode=0 if per_pass == 1 else 1, stride=35,
+                              wavefront=(per_pass, max_blocks))
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+    if per_pass == 1:
+        assert np.array_equal(rng, ref_rng)
+
+
+@needs_block_binary
+def test_wavefront_pass_paths_that_bounce_on(pt, oracle, tmp_path):
+    """all materials, depth 16: paths survive several bounces, so the block-private queues, their ping-pong and the
+    producer-side resolution of terminal hits are all in play"""
+    V, T, M = scenes.all_materials_scene()
+    w, h, spp, depth = 70, 44, 4, 16
+    p = oracle.params(w, h, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=2 + 33 * depth)
+    ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M))
+    assert st.rays_per_bounce[3] > 0
+    img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, rng_mode=1, stride=2 + 33 * depth, wavefront=(4, 5))
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+
+
+@needs_block_binary
+def test_wavefront_pass_extended_shading_on_a_tile(pt, oracle, tmp_path):
+    V, T, M = scenes.mirror_scene()
+    w, h, spp, depth = 64, 36, 4, 12
+    p = oracle.params(w, h, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=2 + 2 * depth, shading=oracle.SHADING_EXTENDED)
+    ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M), pixel_first=300, n=1500)
+    img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, rng_mode=1, stride=2 + 2 * depth, shading=1,
+                            pixel_first=300, pixel_count=1500, wavefront=(2, 2))
     assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
