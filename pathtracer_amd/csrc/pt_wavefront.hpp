@@ -40,6 +40,9 @@ struct PathNext {
 	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
 	float t = 0.0f;
 	uint32_t rng = 0, pid = 0, next_tri = kNoHit;
+	// DEFER: the path ended here and this is its frame value (emitted: it reached a light, else (0,0,0,1))
+	bool done = false, emitted = false;
+	float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
 };
 
 // One lane, one path: the hit h of slot q is shaded (kernels.cu:44-96).  GEN: the camera ray was made by the caller
@@ -47,7 +50,9 @@ struct PathNext {
 // here, so a path whose next hit is terminal -- nothing, an emitter, or (REFERENCE shading) an absorber -- is finished by
 // its producer and never enters the queue; `lit` must then be zero when the pass starts (a finished path writes only if
 // it reached an emitter).
-template <bool FIRST, bool EXTEND, bool GEN, bool RESOLVE>
+// DEFER: a path that ends here stores nothing; the caller gets done / emitted / frame and decides (bounces_block folds
+// them into the mean straight from registers while the pixel's samples are still in order).
+template <bool FIRST, bool EXTEND, bool GEN, bool RESOLVE, bool DEFER = false>
 __device__ __forceinline__ void shade_lane(const ShadeCtx& c, bool extended, uint32_t last_bounce, uint32_t q, uint2 h, float4 gen_b,
                                            const float4* __restrict__ qa, const float4* __restrict__ qb, const float4* __restrict__ qc,
                                            PathNext& r) {
@@ -105,7 +110,11 @@ __device__ __forceinline__ void shade_lane(const ShadeCtx& c, bool extended, uin
 		// REFLECTIVE or anything else: absorbed; a miss: frame stays (0,0,0,1)   :91-93
 		if (c.rng_out) r.rng = __float_as_uint(GEN ? gen_b.w : qb[q].w);
 	}
-	if (!r.cont || last_bounce) {
+	if (DEFER) {
+		r.done = !r.cont || last_bounce;
+		r.emitted = emitted;
+		r.frame = frame;
+	} else if (!r.cont || last_bounce) {
 		// every path that ends sets its flag; only emitter hits carry a radiance, all others are (0,0,0,1)
 		if (!RESOLVE || emitted) c.lit[r.pid] = emitted ? 1 : 0;
 		if (emitted) c.radiance[r.pid] = frame;
@@ -209,7 +218,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
                                               float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
                                               uint32_t* __restrict__ counts, uint32_t* __restrict__ ray_counts,
                                               const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
-                                              uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean) {
+                                              uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending) {
 	const FrameDev& f = c.f;
 	const uint32_t n_tris = c.n_tris;
 	const bool det_bounded = c.det_bounded;
@@ -233,6 +242,11 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 			uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
 			uint32_t r0 = active ? rng_in[li] : 0u;
 			if (strided) r0 = mat_apply(pass_mat, r0);         // start of the pass's first sample
+			// The running mean is order-dependent, so a sample's frame can be folded here, from registers, only while
+			// every earlier sample of the pixel has been: fp = the first sample that went into the queue (n_samples: none).
+			// From fp on, finished samples leave their flag / radiance in memory and the fold at the end takes over.
+			float4 m = active ? mean[li] : float4{ 0, 0, 0, 0 };
+			uint32_t fp = n_samples;
 			for (uint32_t s = 0; s < n_samples; s++) {
 				if (strided && s) r0 = byte_jump(s_stride, r0);
 				PathNext r;
@@ -243,11 +257,18 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 					float best = FLT_MAX;
 					uint32_t ptri = kNoHit;
 					intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri);
-					shade_lane<true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
-					                                  float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
+					shade_lane<true, true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
+					                                        float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
+					if (r.done && fp == n_samples) m = running_mean(r.frame, m, mean_first + s);
+					else {
+						if (fp == n_samples) fp = s;
+						if (r.done && r.emitted) { lit[r.pid] = 1; radiance[r.pid] = r.frame; }      // lit starts at zero
+					}
+					if (r.done && c.rng_out) c.rng_out[r.pid] = r.rng;   // SEQUENTIAL: one sample per pass, pid = local pixel
 				}
 				queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1);
 			}
+			if (active) { mean[li] = m; first_pending[li] = fp; }
 		}
 		if (threadIdx.x == 0) { counts[blockIdx.x] = owned * n_samples; ray_counts[blockIdx.x] = owned * n_samples; }
 	}
@@ -275,8 +296,10 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 	// a10: this block's pixels, the pass's samples folded in order
 	__syncthreads();
 	for (uint32_t li = blockIdx.x * kQueueBlock + threadIdx.x; li < f.pixel_count; li += G * kQueueBlock) {
+		uint32_t fp = first_pending[li];
+		if (fp >= n_samples) continue;                             // every sample was folded where it was made
 		float4 m = mean[li];
-		for (uint32_t s = 0; s < n_samples; s++) {
+		for (uint32_t s = fp; s < n_samples; s++) {
 			size_t p = (size_t)s * f.pixel_count + li;
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };        // kernels.cu:49
 			if (lit[p]) frame = radiance[p];
