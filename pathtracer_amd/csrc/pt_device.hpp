@@ -236,10 +236,13 @@ __device__ __forceinline__ void stage_primary_records(const float4* __restrict__
 	}
 }
 
-// intersect_range for rays from the camera position; best_t / hit_tri as there
+// intersect_range for rays from the camera position; best_t / hit_tri as there.  `need` (wave-uniform, primary_need_mask):
+// bit k clear = no camera ray of this wave's pixels can be accepted by triangle k (k < 64), which is then not tested.
 __device__ __forceinline__ void intersect_range_primary(const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t n,
-                                                        bool det_bounded, Vec3 d, float& best_t, uint32_t& hit_tri) {
+                                                        bool det_bounded, Vec3 d, float& best_t, uint32_t& hit_tri,
+                                                        unsigned long long need = ~0ull) {
 	for (uint32_t k = 0; k < n; k++) {
+		if (k < 64u && !((need >> k) & 1ull)) continue;
 		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
 		Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x };
 		Vec3 h = cross3(d, e1);
@@ -598,6 +601,60 @@ __device__ __forceinline__ Vec3 primary_direction(const FrameDev& f, uint32_t px
 	float pw4 = (bl.w + (br.w - bl.w) * xs) + (tl.w - bl.w) * ys;
 	float inv = rsqrt_ref(px4 * px4 + py4 * py4 + pz4 * pz4 + pw4 * pw4);
 	return Vec3{ px4 * inv, py4 * inv, pz4 * inv };
+}
+
+// ---- which triangles can the camera rays of a pixel reach at all? ----
+// Every sample of pixel (px, py) sends its camera ray through the pixel's own patch of the screen: the unnormalised
+// direction D is affine in the two jitter draws, so it stays in the convex hull of the patch's four corner directions,
+// and the ray that is traced is a positive multiple of it.  Each rejection test of Functions.cuh:72-86 compares
+// quantities that are LINEAR in the direction:
+//     det = D.(e1 x e0) < EPSILON,   u < 0  <=>  A = s.(D x e1) < 0,   u > 1  <=>  A - det > 0,
+//     v < 0  <=>  B = D.q < 0,       u + v > 1  <=>  A + B - det > 0                    (det > 0 where they are reached)
+// so if ONE of them holds at all four corners -- by a margin of 1e-4 of the magnitudes involved, two orders above the
+// fp32 rounding of the traced ray's own arithmetic and of the corners' -- it holds for every ray of the pixel, the test
+// would reject, and the triangle need not be looked at.  A lane works this out once per pixel (per launch or pass), the
+// wave ORs its 64 pixels together (adjacent pixels: they see the same few triangles), and intersect_range_primary skips
+// what no lane needs: on the reference's scene the camera sees one or two of the four triangles.  Culling only skips
+// tests that cannot succeed, so results do not change.  Scenes of more than 64 triangles: everything is "needed".
+__device__ __forceinline__ Vec3 screen_point(const FrameDev& f, float xs, float ys) {
+	float4 bl = f.bottom_left, br = f.bottom_right, tl = f.top_left;
+	return Vec3{ (bl.x + (br.x - bl.x) * xs) + (tl.x - bl.x) * ys, (bl.y + (br.y - bl.y) * xs) + (tl.y - bl.y) * ys,
+	             (bl.z + (br.z - bl.z) * xs) + (tl.z - bl.z) * ys };
+}
+__device__ __forceinline__ float l1norm(Vec3 v) { return fabsf(v.x) + fabsf(v.y) + fabsf(v.z); }
+
+__device__ __forceinline__ unsigned long long primary_need_mask(const FrameDev& f, uint32_t px, uint32_t py, bool active,
+                                                                const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t n_tris) {
+	if (n_tris > 64u) return ~0ull;
+	// the patch: (x + u) / width with u in (0, 1], rounded; IEEE division is monotonic, the fast form returns the same bits
+	float x0 = (float)px / (float)f.width, x1 = ((float)px + 1.0f) / (float)f.width;
+	float y0 = (float)py / (float)f.height, y1 = ((float)py + 1.0f) / (float)f.height;
+	Vec3 c0 = screen_point(f, x0, y0), c1 = screen_point(f, x1, y0), c2 = screen_point(f, x0, y1), c3 = screen_point(f, x1, y1);
+	float dmax = 1e-4f * fmaxf(fmaxf(l1norm(c0), l1norm(c1)), fmaxf(l1norm(c2), l1norm(c3)));
+	unsigned long long need = 0ull;
+	for (uint32_t k = 0; k < n_tris; k++) {
+		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
+		float4 pa = prim[2 * k + 0], pb = prim[2 * k + 1];
+		Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x }, s{ pa.x, pa.y, pa.z }, q{ pb.x, pb.y, pb.z };
+		float ne0 = l1norm(e0), ne1 = l1norm(e1), ns = l1norm(s), nq = l1norm(q);
+		float m_det = dmax * ne0 * ne1, m_a = dmax * ns * ne1, m_b = dmax * nq;
+		float m_u1 = m_a + m_det, m_uv1 = m_a + m_b + m_det;
+		bool det_neg = true, a_neg = true, b_neg = true, u_gt1 = true, uv_gt1 = true;
+		const Vec3 corner[4] = { c0, c1, c2, c3 };
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			Vec3 h = cross3(corner[c], e1);
+			float det = dot3(e0, h), a = dot3(s, h), b = dot3(corner[c], q);
+			det_neg = det_neg && det < -m_det;
+			a_neg = a_neg && a < -m_a;
+			b_neg = b_neg && b < -m_b;
+			u_gt1 = u_gt1 && a - det > m_u1;
+			uv_gt1 = uv_gt1 && a + b - det > m_uv1;
+		}
+		bool can_hit = active && !(det_neg || a_neg || b_neg || u_gt1 || uv_gt1);
+		if (__ballot(can_hit) != 0ull) need |= 1ull << k;
+	}
+	return need;
 }
 
 // DrawToTexture's running mean, kernels.cu:17-18.

@@ -429,6 +429,9 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 		if (STRIDED) start = mat_apply_lds(s_first, start);
 		uint32_t rng = start;
 		float4 m = mean_io[li];
+		// the triangles this wave's pixels can see at all (none of the lanes here is out of range: the loop bound holds for li)
+		unsigned long long need = ~0ull;
+		if (use_prim) need = primary_need_mask(f, px, py, true, tris, s_prim, n_tris);
 		for (uint32_t s = 0; s < n_samples; s++) {
 			Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
 			Vec3 d = primary_direction(f, px, py, rng);
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_fused(FrameDev f, const unsigned cha
 				uint32_t tri = kNoHit;
 				if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
 				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
-				else if (b == 0 && use_prim) intersect_range_primary(tris, s_prim, n_tris, det_bounded, d, best, tri);
+				else if (b == 0 && use_prim) intersect_range_primary(tris, s_prim, n_tris, det_bounded, d, best, tri, need);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				if (tri == kNoHit) break;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];

@@ -247,6 +247,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 			// From fp on, finished samples leave their flag / radiance in memory and the fold at the end takes over.
 			float4 m = active ? mean[li] : float4{ 0, 0, 0, 0 };
 			uint32_t fp = n_samples;
+			const unsigned long long need = primary_need_mask(f, px, py, active, c.tris, s_prim, n_tris);   // every lane of the block is here
 			for (uint32_t s = 0; s < n_samples; s++) {
 				if (strided && s) r0 = byte_jump(s_stride, r0);
 				PathNext r;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 					Vec3 gd = primary_direction(f, px, py, rs);
 					float best = FLT_MAX;
 					uint32_t ptri = kNoHit;
-					intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri);
+					intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri, need);
 					shade_lane<true, true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
 					                                        float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
 					if (r.done && fp == n_samples) m = running_mean(r.frame, m, mean_first + s);

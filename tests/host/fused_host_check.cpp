@@ -76,6 +76,8 @@ int main(int argc, char** argv) {
 		if (STRIDED) start = steps(start, (unsigned long long)frame_first * f.stride);
 		uint32_t rng = start;
 		float4 m = mean[li];
+		unsigned long long need = ~0ull;
+		if (use_prim) need = primary_need_mask(f, px, py, true, tris, prim.data(), n_tris);
 		for (uint32_t s = 0; s < n_samples; s++) {
 			Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
 			Vec3 d = primary_direction(f, px, py, rng);
@@ -88,7 +90,7 @@ int main(int argc, char** argv) {
 				uint32_t tri = kNoHit;
 				if (extended) best = FLT_MAX;
 				if (BVH) bvh_intersect(bv, o, d, best, tri, stack.data());
-				else if (b == 0 && use_prim) intersect_range_primary(tris, prim.data(), n_tris, det_bounded, d, best, tri);
+				else if (b == 0 && use_prim) intersect_range_primary(tris, prim.data(), n_tris, det_bounded, d, best, tri, need);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				if (tri == kNoHit) break;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
