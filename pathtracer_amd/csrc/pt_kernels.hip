@@ -312,7 +312,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
                                                        uint32_t* __restrict__ counts, uint32_t* __restrict__ ray_counts, uint32_t capacity,
                                                        float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out,
                                                        const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
-                                                       uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending) {
+                                                       uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending,
+                                                       unsigned long long* __restrict__ need_masks, uint32_t need_masks_valid) {
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_stride[1024];       // STRIDED: byte tables of step^stride
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
 	__syncthreads();
 	ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
-	bounces_block(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, counts, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending);
+	bounces_block(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, counts, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending, need_masks, need_masks_valid != 0u);
 }
 
 // a10. One thread per pixel, the pass's samples folded in order.
@@ -528,6 +529,7 @@ struct Workspace {
 	uint32_t* ray_counts; // same shape: rays traced per bounce, where terminal hits never enter the queue (k_shade RESOLVE)
 	uint32_t* smat;      // max(samples_per_pass, 2) x 32 words (STRIDED)
 	uint32_t* first_pending;   // per pixel: the first sample of the pass whose frame the one-launch pass did not fold from registers
+	unsigned long long* need_masks;   // per 64 pixels: the triangles their camera rays can reach (primary_need_mask), kept across the passes of a call
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Queue capacity of a pass.  The one-launch pass (k_bounces) gives block b the pixel chunks {k : k % G == b} with all
@@ -554,6 +556,7 @@ size_t carve(Workspace* w, unsigned char* base, uint32_t pixel_count, uint32_t s
 	w->ray_counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
 	w->smat = (uint32_t*)take((size_t)std::max(samples_per_pass, 2u) * 32 * 4);
 	w->first_pending = (uint32_t*)take((size_t)pixel_count * 4);
+	w->need_masks = (unsigned long long*)take((((size_t)pixel_count + kBlock - 1) / kBlock) * (kBlock / 64) * 8);
 	return off;
 }
 
@@ -921,7 +924,7 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 			hipLaunchKernelGGL(k_bounces, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats,
 			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1],
 			                   w.counts, w.ray_counts, slots, w.radiance, w.lit, sequential ? rng : nullptr,
-			                   (const uint32_t*)w.smat, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending);
+			                   (const uint32_t*)w.smat, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending, w.need_masks, done != 0u ? 1u : 0u);
 		} else {
 			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
 			if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;

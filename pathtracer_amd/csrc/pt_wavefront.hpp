@@ -218,7 +218,8 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
                                               float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
                                               uint32_t* __restrict__ counts, uint32_t* __restrict__ ray_counts,
                                               const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
-                                              uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending) {
+                                              uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending,
+                                              unsigned long long* __restrict__ need_masks, bool need_masks_valid) {
 	const FrameDev& f = c.f;
 	const uint32_t n_tris = c.n_tris;
 	const bool det_bounded = c.det_bounded;
@@ -247,7 +248,15 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 			// From fp on, finished samples leave their flag / radiance in memory and the fold at the end takes over.
 			float4 m = active ? mean[li] : float4{ 0, 0, 0, 0 };
 			uint32_t fp = n_samples;
-			const unsigned long long need = primary_need_mask(f, px, py, active, c.tris, s_prim, n_tris);   // every lane of the block is here
+			// which triangles this wave's 64 pixels can see: worked out in the first pass of a render call, kept per wave
+			// (one word per 64 pixels) for the passes that follow -- it depends on the pixels and the camera only
+			unsigned long long need;
+			const uint32_t wave_slot = li0 / 64u + (threadIdx.x >> 6);
+			if (need_masks_valid) need = need_masks[wave_slot];
+			else {
+				need = primary_need_mask(f, px, py, active, c.tris, s_prim, n_tris);                       // every lane of the block is here
+				if ((threadIdx.x & 63u) == 0u) need_masks[wave_slot] = need;
+			}
 			for (uint32_t s = 0; s < n_samples; s++) {
 				if (strided && s) r0 = byte_jump(s_stride, r0);
 				PathNext r;

@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
 	float4* mean = exact<float4>(N);
 	uint32_t* rng = exact<uint32_t>(N);
 	uint32_t* first_pending = exact<uint32_t>(N);
+	unsigned long long* need_masks = exact<unsigned long long>((size_t)chunks * 4);
 	for (uint32_t li = 0; li < N; li++) { mean[li] = float4{ 1.0f, 1.0f, 1.0f, 1.0f }; rng[li] = steps(f.seed + f.pixel_first + li, (f.pixel_first + li) >> 5); }
 
 	// the block's LDS
@@ -116,7 +117,7 @@ int main(int argc, char** argv) {
 					__syncthreads();
 					ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, (uint32_t)slots, radiance, lit, sequential ? rng : nullptr, &s_out, &s_traced };
 					bounces_block(c, s_scene + nt4 + nm2, s_stride, qa[0], qb[0], qc[0], qpid[0], qhit[0], qa[1], qb[1], qc[1], qpid[1], qhit[1],
-					              counts, ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending);
+					              counts, ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0);
 				});
 			for (auto& t : th) t.join();
 		}
