@@ -238,26 +238,35 @@ __device__ __forceinline__ void stage_primary_records(const float4* __restrict__
 
 // intersect_range for rays from the camera position; best_t / hit_tri as there.  `need` (wave-uniform, primary_need_mask):
 // bit k clear = no camera ray of this wave's pixels can be accepted by triangle k (k < 64), which is then not tested.
+__device__ __forceinline__ void primary_triangle(const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t k,
+                                                 bool det_bounded, Vec3 d, float& best_t, uint32_t& hit_tri) {
+	float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
+	Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x };
+	Vec3 h = cross3(d, e1);
+	float det = dot3(e0, h);
+	if (det < kEpsilon) return;                   // Functions.cuh:72
+	float f;                                      // :77
+	if (det_bounded) f = rcp_newton(det); else f = 1.0f / det;
+	float4 pa = prim[2 * k + 0];
+	float u = f * dot3(Vec3{ pa.x, pa.y, pa.z }, h);   // :80
+	if (u < 0.0f || u > 1.0f) return;
+	float4 pb = prim[2 * k + 1];
+	float v = f * dot3(d, Vec3{ pb.x, pb.y, pb.z });   // :84
+	if (v < 0.0f || u + v > 1.0f) return;
+	float t = f * pa.w;                           // :87
+	if (t > kEpsilon && t < best_t) { best_t = t; hit_tri = k; }   // kernels.cu:64
+}
+
 __device__ __forceinline__ void intersect_range_primary(const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t n,
                                                         bool det_bounded, Vec3 d, float& best_t, uint32_t& hit_tri,
                                                         unsigned long long need = ~0ull) {
-	for (uint32_t k = 0; k < n; k++) {
-		if (k < 64u && !((need >> k) & 1ull)) continue;
-		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
-		Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x };
-		Vec3 h = cross3(d, e1);
-		float det = dot3(e0, h);
-		if (det < kEpsilon) continue;                 // Functions.cuh:72
-		float f;                                      // :77
-		if (det_bounded) f = rcp_newton(det); else f = 1.0f / det;
-		float4 pa = prim[2 * k + 0];
-		float u = f * dot3(Vec3{ pa.x, pa.y, pa.z }, h);   // :80
-		if (u < 0.0f || u > 1.0f) continue;
-		float4 pb = prim[2 * k + 1];
-		float v = f * dot3(d, Vec3{ pb.x, pb.y, pb.z });   // :84
-		if (v < 0.0f || u + v > 1.0f) continue;
-		float t = f * pa.w;                           // :87
-		if (t > kEpsilon && t < best_t) { best_t = t; hit_tri = k; }   // kernels.cu:64
+	if (n <= 64u) {
+		// walk the set bits in ascending order (ties go to the lower index, kernels.cu:64): the loop runs once per needed
+		// triangle, not once per triangle with a skip
+		unsigned long long m = n == 64u ? need : need & ((1ull << n) - 1ull);
+		for (; m != 0ull; m &= m - 1ull) primary_triangle(tris, prim, (uint32_t)__builtin_ctzll(m), det_bounded, d, best_t, hit_tri);
+	} else {
+		for (uint32_t k = 0; k < n; k++) primary_triangle(tris, prim, k, det_bounded, d, best_t, hit_tri);
 	}
 }
 
