@@ -124,14 +124,17 @@ __device__ __forceinline__ void shade_lane(const ShadeCtx& c, bool extended, uin
 
 // wave64 compaction of the continuing paths into this block's own slots of the output queue: ballot + prefix, one LDS
 // add per wave.  Every lane of the wave calls it.
+// traced_acc (RESOLVE): when given, the wave's count of traced rays is added to it (wave-uniform) instead of to the LDS
+// counter; the caller adds the total once (one LDS atomic per chunk of camera rays rather than one per sample).
 template <bool EXTEND, bool RESOLVE>
 __device__ __forceinline__ void queue_push(const ShadeCtx& c, uint32_t last_bounce, const PathNext& r,
                                            float4* __restrict__ oa, float4* __restrict__ ob, float4* __restrict__ oc,
-                                           uint32_t* __restrict__ opid, uint2* __restrict__ ohit) {
+                                           uint32_t* __restrict__ opid, uint2* __restrict__ ohit, uint32_t* traced_acc = nullptr) {
 	const uint32_t lane = threadIdx.x & 63u;
 	if (RESOLVE) {
 		uint32_t n_traced = (uint32_t)__popcll(__ballot(r.traced));
-		if (n_traced && lane == 0) atomicAdd(c.s_traced, n_traced);
+		if (traced_acc) *traced_acc += n_traced;
+		else if (n_traced && lane == 0) atomicAdd(c.s_traced, n_traced);
 	}
 	unsigned long long mask = __ballot(r.cont);
 	uint32_t n_cont = (uint32_t)__popcll(mask);
@@ -248,6 +251,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 			// From fp on, finished samples leave their flag / radiance in memory and the fold at the end takes over.
 			float4 m = active ? mean[li] : float4{ 0, 0, 0, 0 };
 			uint32_t fp = n_samples;
+			uint32_t traced_acc = 0;                            // wave-uniform: rays this wave traced for bounce 1 in this chunk
 			// which triangles this wave's 64 pixels can see: worked out in the first pass of a render call, kept per wave
 			// (one word per 64 pixels) for the passes that follow -- it depends on the pixels and the camera only
 			unsigned long long need;
@@ -276,8 +280,9 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 					}
 					if (r.done && c.rng_out) c.rng_out[r.pid] = r.rng;   // SEQUENTIAL: one sample per pass, pid = local pixel
 				}
-				queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1);
+				queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1, &traced_acc);
 			}
+			if (traced_acc && (threadIdx.x & 63u) == 0u) atomicAdd(c.s_traced, traced_acc);
 			if (active) { mean[li] = m; first_pending[li] = fp; }
 		}
 		if (threadIdx.x == 0) { counts[blockIdx.x] = owned * n_samples; ray_counts[blockIdx.x] = owned * n_samples; }
