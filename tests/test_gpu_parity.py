@@ -33,6 +33,42 @@ def test_default_scene_sequential(pt, oracle, name, engine, w, h, spp):
     assert st.frames == spp
 
 
+@pytest.mark.parametrize("name,engine,mode", [("fused", 1, "sequential"), ("wavefront", 0, "strided")])
+def test_headline_config_every_pixel(pt, oracle, name, engine, mode):
+    """BASELINE.json configs[1] at full size -- 1920x1080, 64 spp, depth 10, seed 1337 -- as bench.py runs it (the fused
+    engine on the reference's sequential streams, the wavefront engine on strided/35 in passes of 16): all 2 073 600 pixels
+    against the oracle (on the box's host threads, ~2 s), bit for bit, plus the ray count 2 x pixels x samples."""
+    w, h, spp = 1920, 1080, 64
+    strided = mode == "strided"
+    ref, _, ref_stats, _ = oracle.render(oracle.params(w, h, spp=spp, rng_mode=oracle.RNG_STRIDED if strided else oracle.RNG_SEQUENTIAL, stride=35))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED if strided else pt.PT_RNG_SEQUENTIAL, stride=35, samples_per_pass=16)
+        tr.render(spp)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, ref, f"{name} 1920x1080x64")
+    assert st.rays == ref_stats.rays == 2 * w * h * spp
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_4k_share_of_one_rank_every_pixel(pt, oracle, name, engine):
+    """BASELINE.json configs[2], the share of rank 3 of 8 at full image size: 3840x2160, strided/35, samples 384..399 of the
+    1024-sample frame (16 of the rank's 128, to keep the oracle's side at a few seconds): all 8 294 400 pixels, bit for bit."""
+    w, h, spp, first = 3840, 2160, 16, 3 * 128
+    ones = np.ones((w * h, 4), dtype=np.float32)
+    ref = ones
+    # the oracle numbers the running mean from frame_first; the plugin's shard starts its own mean at 0: fold frame by frame
+    for s_ in range(spp):
+        _, _, _, frame = oracle.render(oracle.params(w, h, spp=1, rng_mode=oracle.RNG_STRIDED, stride=35, frame_first=first + s_), want_last_frame=True)
+        r = np.float32(1.0) / np.float32(s_ + 1)
+        ref = (frame * r + (ref * np.float32(s_)) * r).astype(np.float32)
+    with pt.PathTracer(w, h) as tr:
+        tr.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, samples_per_pass=8, sample_offset=first)
+        tr.render(spp)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, ref, f"{name} 3840x2160 samples {first}..{first + spp - 1}")
+    assert st.rays == 2 * w * h * spp
+
+
 @pytest.mark.parametrize("name,engine", ENGINES)
 def test_begin_finalize_equals_batched(pt, oracle, name, engine):
     w, h, spp = 96, 64, 5
