@@ -155,3 +155,16 @@ def test_wavefront_pass_extended_shading_on_a_tile(pt, oracle, tmp_path):
     img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, rng_mode=1, stride=2 + 2 * depth, shading=1,
                             pixel_first=300, pixel_count=1500, wavefront=(2, 2))
     assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+
+
+@needs_block_binary
+def test_wavefront_pass_at_the_depth_limit(pt, oracle, tmp_path):
+    """PT_MAX_DEPTH = 32 bounce iterations on the mirror scene (extended shading keeps most paths alive to the end): the
+    per-bounce counter rows, the queue ping-pong and the last-bounce handling at their limit."""
+    V, T, M = scenes.mirror_scene()
+    w, h, spp, depth = 40, 24, 3, 32
+    p = oracle.params(w, h, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=2 + 2 * depth, shading=oracle.SHADING_EXTENDED)
+    ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M))
+    assert st.rays_per_bounce[31] > 0
+    img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, rng_mode=1, stride=2 + 2 * depth, shading=1, wavefront=(3, 2))
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays

@@ -70,6 +70,27 @@ def test_4k_share_of_one_rank_every_pixel(pt, oracle, name, engine):
 
 
 @pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("shading", [0, 1])
+def test_depth_limit(pt, oracle, name, engine, shading):
+    """PT_MAX_DEPTH = 32 bounce iterations: all materials under reference shading (strided/1058 so that the wavefront engine
+    batches), the mirror scene under extended shading (paths alive at bounce 31)."""
+    V, T, M = scenes.mirror_scene() if shading else scenes.all_materials_scene()
+    w, h, spp, depth = 120, 68, 5, 32
+    stride = 2 + (2 if shading else 33) * depth
+    ref, _, st_ref, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=stride, shading=shading),
+                                      scene=oracle.make_scene(V, T, M))
+    if shading:
+        assert st_ref.rays_per_bounce[31] > 0
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=3, shading=shading)
+        tr.render(spp)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, ref, f"{name} depth 32 shading {shading}")
+    assert st.rays == st_ref.rays
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
 def test_begin_finalize_equals_batched(pt, oracle, name, engine):
     w, h, spp = 96, 64, 5
     ref, _, _, _ = oracle.render(oracle.params(w, h, spp=spp))
