@@ -168,3 +168,12 @@ def test_wavefront_pass_at_the_depth_limit(pt, oracle, tmp_path):
     assert st.rays_per_bounce[31] > 0
     img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, rng_mode=1, stride=2 + 2 * depth, shading=1, wavefront=(3, 2))
     assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+
+
+@needs_block_binary
+@pytest.mark.parametrize("w,h", [(1, 1), (257, 1), (3, 200)])
+def test_wavefront_pass_degenerate_image_shapes(pt, oracle, tmp_path, w, h):
+    spp = 5
+    ref, _, st, _ = oracle.render(oracle.params(w, h, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=35))
+    img, _, rays = run_host(pt, oracle, tmp_path, scenes.default_scene(), w, h, spp, rng_mode=1, stride=35, wavefront=(2, 8))
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays

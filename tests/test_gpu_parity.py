@@ -70,6 +70,22 @@ def test_4k_share_of_one_rank_every_pixel(pt, oracle, name, engine):
 
 
 @pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 7), (257, 1), (3, 1000), (255, 3), (4099, 2)])
+def test_degenerate_image_shapes(pt, oracle, name, engine, w, h):
+    """one pixel, one column, one row just over a block, sizes around the 256-pixel chunk and a prime width: sequential
+    streams, then strided ones in passes of 2 (a short last pass)"""
+    for strided in (False, True):
+        spp = 5
+        ref, _, st_ref, _ = oracle.render(oracle.params(w, h, spp=spp, rng_mode=oracle.RNG_STRIDED if strided else oracle.RNG_SEQUENTIAL, stride=35))
+        with pt.PathTracer(w, h) as tr:
+            tr.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED if strided else pt.PT_RNG_SEQUENTIAL, stride=35, samples_per_pass=2)
+            tr.render(spp)
+            img, st = tr.readback(), tr.stats()
+        assert_bit_equal(img, ref, f"{name} {w}x{h} strided={strided}")
+        assert st.rays == st_ref.rays
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
 @pytest.mark.parametrize("shading", [0, 1])
 def test_depth_limit(pt, oracle, name, engine, shading):
     """PT_MAX_DEPTH = 32 bounce iterations: all materials under reference shading (strided/1058 so that the wavefront engine
