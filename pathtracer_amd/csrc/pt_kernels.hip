@@ -73,6 +73,18 @@ int grid_for(size_t work_items) {
 	return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
 
+// Grid of the one-launch wavefront pass (k_bounces): blocks own pixel chunks and run to completion on their own, so a grid
+// of MORE blocks than fit the machine at once lets the dispatcher back-fill a CU as soon as one of its blocks is done --
+// load balancing for free where blocks differ in how long their paths live.  Measured (1080p, 16 samples per pass; 8 / 16
+// / 32 blocks per CU): default scene 182 / 197 / 200 Grays/s, C5 24.6 / 26.8 / 29.0, C5 mirror scene 16.5 / 17.9 / 19.2; at
+// 3840x2160 32 per CU beats both 8 and one chunk per block.  (The staged BVH pipeline prefers 8: its persistent traversal
+// refills lanes from the block's own queue, and a short queue refills badly.)
+int grid_for_pass(uint32_t pixel_count) {
+	size_t chunks = ((size_t)pixel_count + kBlock - 1) / kBlock;
+	size_t cap = (size_t)grid_for((size_t)1 << 40) * 4;      // grid_for's cap is 8 blocks per CU: 32 here
+	return (int)std::max<size_t>(1, std::min(chunks, cap));
+}
+
 FrameDev to_dev(const pt_frame& f) {
 	FrameDev d;
 	d.width = f.width; d.height = f.height;
@@ -533,11 +545,11 @@ struct Workspace {
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Queue capacity of a pass.  The one-launch pass (k_bounces) gives block b the pixel chunks {k : k % G == b} with all
-// samples, G = grid_for(pixel_count), so every block needs ceil(chunks/G) * samples_per_pass rows of 256 slots: the
+// samples, G = grid_for_pass(pixel_count), so every block needs ceil(chunks/G) * samples_per_pass rows of 256 slots: the
 // path count rounded up to whole rows for every block (at most one chunk-row of padding per block).
 size_t queue_capacity(uint32_t pixel_count, uint32_t samples_per_pass) {
 	size_t chunks = ((size_t)pixel_count + kBlock - 1) / kBlock;
-	size_t G = (size_t)grid_for(pixel_count);
+	size_t G = (size_t)grid_for_pass(pixel_count);
 	return G * ((chunks + G - 1) / G) * samples_per_pass * kBlock;
 }
 
@@ -552,8 +564,9 @@ size_t carve(Workspace* w, unsigned char* base, uint32_t pixel_count, uint32_t s
 	w->hit[0] = (uint2*)take(slots * 8); w->hit[1] = (uint2*)take(slots * 8);
 	w->radiance = (float4*)take(paths * 16);
 	w->lit = (unsigned char*)take(paths);
-	w->counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
-	w->ray_counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * grid_for(paths) * 4);
+	size_t max_blocks = (size_t)std::max(grid_for(paths), grid_for_pass(pixel_count));
+	w->counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * max_blocks * 4);
+	w->ray_counts = (uint32_t*)take((size_t)(PT_MAX_DEPTH + 2) * max_blocks * 4);
 	w->smat = (uint32_t*)take((size_t)std::max(samples_per_pass, 2u) * 32 * 4);
 	w->first_pending = (uint32_t*)take((size_t)pixel_count * 4);
 	w->need_masks = (unsigned long long*)take((((size_t)pixel_count + kBlock - 1) / kBlock) * (kBlock / 64) * 8);
@@ -908,7 +921,7 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	// scene resident in LDS: the whole pass is one launch (k_bounces)
 	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si);
 	// queue blocks: fixed for every stage of every pass
-	const uint32_t G = (uint32_t)(fuse ? grid_for(frame->pixel_count) : grid_for(paths_cap));
+	const uint32_t G = (uint32_t)(fuse ? grid_for_pass(frame->pixel_count) : grid_for(paths_cap));
 	const uint32_t slots = (uint32_t)queue_capacity(frame->pixel_count, samples_per_pass);
 
 	for (uint32_t done = 0; done < n_samples; done += samples_per_pass) {
