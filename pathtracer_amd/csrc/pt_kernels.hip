@@ -452,14 +452,9 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 1 : 8) void k_fused(FrameDev f
 			float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
 			uint32_t draws = 2;                      // this sample's RNG draws: 2 + 33 per diffuse bounce
-			for (uint32_t b = 0; b < f.depth; b++) {
-				n_rays++;
-				uint32_t tri = kNoHit;
-				if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
-				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
-				else if (b == 0 && use_prim) intersect_range_primary(tris, s_prim, n_tris, det_bounded, d, best, tri, need);
-				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
-				if (tri == kNoHit) break;
+			// Intersect (kernels.cu:71-94) for the hit `tri`; true if the path goes on
+			auto shade_hit = [&](uint32_t tri) -> bool {
+				if (tri == kNoHit) return false;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
 				uint32_t mi = __float_as_uint(r3.x);
 				float4 head = mats[2 * mi];
@@ -467,15 +462,36 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 1 : 8) void k_fused(FrameDev f
 				float4 color = mats[2 * mi + 1];
 				if (extended && type != PT_MAT_EMISSIVE) {
 					if (shade_extended(type, Vec3{ r2.y, r2.z, r2.w }, color, head.y, best, o, d, step, rng)) { n_diffuse++; draws += 2; }
-				} else if (type == PT_MAT_DIFFUSE) {
+					return true;
+				}
+				if (type == PT_MAT_DIFFUSE) {
 					shade_diffuse(Vec3{ r2.y, r2.z, r2.w }, color, best, s_jump, o, d, step, rng);
 					n_diffuse++;
 					draws += 33;
-				} else {
-					if (type == PT_MAT_EMISSIVE)
-						frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };
-					break;
+					return true;
 				}
+				if (type == PT_MAT_EMISSIVE)
+					frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };
+				return false;
+			};
+			// bounce 0, the camera ray, stands apart from the loop: its intersection is a different routine, and straight-line
+			// code here spares every sample the loop's first trip through its branches
+			bool alive = f.depth > 0u;
+			if (alive) {
+				n_rays++;
+				uint32_t tri = kNoHit;
+				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+				else if (use_prim) intersect_range_primary(tris, s_prim, n_tris, det_bounded, d, best, tri, need);
+				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
+				alive = shade_hit(tri);
+			}
+			for (uint32_t b = 1; alive && b < f.depth; b++) {
+				n_rays++;
+				uint32_t tri = kNoHit;
+				if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
+				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
+				alive = shade_hit(tri);
 			}
 			m = running_mean(frame, m, mean_first + s);
 			if (STRIDED) {
