@@ -91,10 +91,11 @@ def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, cam
     assert int(fields[1]) == n_rays and int(fields[3]) > n_rays // 3 and int(fields[5]) == 0, r.stdout
 
 
-@pytest.mark.parametrize("name,n_rays,lanes", [("synthetic-1500", 2500, 64), ("synthetic-10000", 700, 64), ("mixed", 1500, 64), ("synthetic-700", 333, 37)])
-def test_extend_stage_as_a_wave_of_host_threads(pt, tmp_path, name, n_rays, lanes):
+@pytest.mark.parametrize("name,n_rays,lanes,first", [("synthetic-1500", 2500, 64, 0), ("synthetic-10000", 700, 64, 0), ("mixed", 1500, 64, 0),
+                                                     ("synthetic-700", 333, 37, 0), ("synthetic-2500", 1200, 64, 1)])
+def test_extend_stage_as_a_wave_of_host_threads(pt, tmp_path, name, n_rays, lanes, first):
     """extend_bvh_block (what k_extend<false, true> runs) with diverging rays: every queue slot gets the brute-force hit.
-    37 lanes: a partial wave, a ray count that is no multiple of it."""
+    37 lanes: a partial wave, a ray count that is no multiple of it.  first = 1: the bounce-0 form, rays from the camera."""
     if not os.path.exists(WAVE_CHECK):
         pytest.skip("tests/host/extend_wave_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
     V, T, M = mixed_scene() if name == "mixed" else scenes.synthetic_scene(int(name.split("-")[1]))
@@ -104,7 +105,7 @@ def test_extend_stage_as_a_wave_of_host_threads(pt, tmp_path, name, n_rays, lane
     make_rays(n_rays, 11, camera).tofile(rays)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     env.pop("LD_PRELOAD", None)
-    r = subprocess.run([WAVE_CHECK, str(blob), str(rays)] + [str(c) for c in camera] + [str(lanes)], capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run([WAVE_CHECK, str(blob), str(rays)] + [str(c) for c in camera] + [str(lanes), str(first)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     fields = r.stdout.split()
     assert int(fields[1]) == n_rays and int(fields[3]) > n_rays // 3 and int(fields[5]) == 0, r.stdout
