@@ -436,6 +436,9 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack);
 }
 
+#ifndef PT_BVH_REFILL
+#define PT_BVH_REFILL 32     // idle lanes at which a wave refills; measured 4 / 8 / 16 / 32 / 40 / 48 / 56 on the 10 092-triangle scene: 4.70 / 4.74 / 4.92 / 5.18 / 5.20 / 5.05 / 4.71 Grays/s
+#endif
 constexpr uint32_t kQueueBlock = 256;       // lanes per block == slots per queue row (pt_kernels.hip kBlock)
 
 // The extend stage of one block over its own queue entries, BVH scenes (k_extend<FIRST, true>).
@@ -463,8 +466,9 @@ __device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origi
 		if (idle && has_ray) { hit[q] = uint2{ __float_as_uint(best), tri }; has_ray = false; }
 		unsigned long long idle_mask = __ballot(idle);
 		uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-		// refill when a quarter of the wave idles (the set-up of a ray costs about as much as two node steps)
-		if (!exhausted && (n_idle >= 16u || n_idle == 64u)) {
+		// refill when half of the wave idles (the set-up of a ray costs about as much as two node steps, and every refill
+		// stalls the lanes that are still walking)
+		if (!exhausted && (n_idle >= (uint32_t)PT_BVH_REFILL || n_idle == 64u)) {
 			uint32_t base = 0;
 			if (lane == 0) base = atomicAdd(s_next, n_idle);
 			base = __shfl(base, 0, 64);

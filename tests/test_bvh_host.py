@@ -91,7 +91,7 @@ def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, cam
     assert int(fields[1]) == n_rays and int(fields[3]) > n_rays // 3 and int(fields[5]) == 0, r.stdout
 
 
-@pytest.mark.parametrize("name,n_rays,lanes,first", [("synthetic-1500", 2500, 64, 0), ("synthetic-10000", 700, 64, 0), ("mixed", 1500, 64, 0),
+@pytest.mark.parametrize("name,n_rays,lanes,first", [("synthetic-1500", 1400, 64, 0), ("synthetic-10000", 700, 64, 0), ("mixed", 1500, 64, 0),
                                                      ("synthetic-700", 333, 37, 0), ("synthetic-2500", 1200, 64, 1)])
 def test_extend_stage_as_a_wave_of_host_threads(pt, tmp_path, name, n_rays, lanes, first):
     """extend_bvh_block (what k_extend<false, true> runs) with diverging rays: every queue slot gets the brute-force hit.
