@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
 	BvhView bv = make_bvh_view(blob, n_tris, n_mats, camera);
 	size_t depth = bvh_stack_depth(n_tris);
 	uint32_t* stack = (uint32_t*)std::malloc(depth * 256 * sizeof(uint32_t));      // [level][256 lanes], lane 0 used
+	std::memset(stack, 0xDB, depth * 256 * sizeof(uint32_t));                       // LDS is not zero on the device
 	const float* rays = reinterpret_cast<const float*>(rays_v.data());
 	size_t n_rays = rays_v.size() / (7 * sizeof(float)), bad = 0, hits = 0;
 	for (size_t k = 0; k < n_rays; k++) {

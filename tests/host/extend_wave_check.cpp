@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
 		qa[k] = float4{ r[0], r[1], r[2], r[3] };
 		qb[k] = first ? float4{ r[3], r[4], r[5], 0.0f } : float4{ r[4], r[5], r[6], 0.0f };
 	}
-	std::vector<uint32_t> s_stack((size_t)bvh_stack_depth(n_tris) * 256);
+	std::vector<uint32_t> s_stack((size_t)bvh_stack_depth(n_tris) * 256, 0xDEADBEEFu);      // LDS is not zero on the device: a slot read before it is written must show
 	uint32_t s_next = 0;
 	WaveShim wave;
 	wave.lanes = lanes;
