@@ -28,7 +28,13 @@ static std::vector<unsigned char> read_file(const char* path) {
 }
 
 static uint32_t steps(uint32_t x, unsigned long long k) { while (k--) x = xs_step(x); return x; }
-template <typename T> static T* exact(size_t n) { return (T*)std::calloc(n ? n : 1, sizeof(T)); }      // n == 0: a valid pointer nobody may index
+// exact size (ASan guards both ends), filled with garbage: neither the workspace nor LDS is zero on the device, so a slot
+// that is read before it is written must show.  n == 0: a valid pointer nobody may index.
+template <typename T> static T* exact(size_t n) {
+	T* p = (T*)std::malloc((n ? n : 1) * sizeof(T));
+	std::memset(p, 0xDB, (n ? n : 1) * sizeof(T));
+	return p;
+}
 
 int main(int argc, char** argv) {
 	if (argc < 8) { std::fprintf(stderr, "usage: bounces_block_check blob frame frame_first n_samples samples_per_pass max_blocks out\n"); return 2; }
