@@ -592,6 +592,21 @@ struct FrameDev {
 	float4   origin, top_left, bottom_left, bottom_right;
 };
 
+// The kernel-side form of a pt_frame (host code: the library's entry points and the host harnesses of tests/host).
+inline FrameDev to_dev(const pt_frame& f) {
+	FrameDev d;
+	d.width = f.width; d.height = f.height;
+	d.pixel_first = f.pixel_first; d.pixel_count = f.pixel_count;
+	d.depth = f.depth; d.seed = f.seed; d.rng_mode = f.rng_mode; d.stride = f.stride; d.shading = f.shading;
+	d.fast_div = (f.flags & PT_FRAME_FAST_DIV) ? 1u : 0u;
+	d.rcp_width = 1.0f / (float)f.width; d.rcp_height = 1.0f / (float)f.height;      // host IEEE division: correctly rounded
+	d.origin = float4{ f.origin.x, f.origin.y, f.origin.z, f.origin.w };
+	d.top_left = float4{ f.top_left.x, f.top_left.y, f.top_left.z, f.top_left.w };
+	d.bottom_left = float4{ f.bottom_left.x, f.bottom_left.y, f.bottom_left.z, f.bottom_left.w };
+	d.bottom_right = float4{ f.bottom_right.x, f.bottom_right.y, f.bottom_right.z, f.bottom_right.w };
+	return d;
+}
+
 // a / b with rb = RN(1 / b): q0 = a * rb, then two residual corrections q += fma(-q, b, a) * rb (Markstein: with a correctly
 // rounded reciprocal and a faithful q the corrected quotient is the correctly rounded one; the first correction makes q
 // faithful).  Used only under PT_FRAME_FAST_DIV, i.e. after pt_hip_verify_fast_div has compared it with the IEEE division

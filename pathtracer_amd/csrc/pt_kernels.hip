@@ -85,20 +85,6 @@ int grid_for_pass(uint32_t pixel_count) {
 	return (int)std::max<size_t>(1, std::min(chunks, cap));
 }
 
-FrameDev to_dev(const pt_frame& f) {
-	FrameDev d;
-	d.width = f.width; d.height = f.height;
-	d.pixel_first = f.pixel_first; d.pixel_count = f.pixel_count;
-	d.depth = f.depth; d.seed = f.seed; d.rng_mode = f.rng_mode; d.stride = f.stride; d.shading = f.shading;
-	d.fast_div = (f.flags & PT_FRAME_FAST_DIV) ? 1u : 0u;
-	d.rcp_width = 1.0f / (float)f.width; d.rcp_height = 1.0f / (float)f.height;      // host IEEE division: correctly rounded
-	d.origin = float4{ f.origin.x, f.origin.y, f.origin.z, f.origin.w };
-	d.top_left = float4{ f.top_left.x, f.top_left.y, f.top_left.z, f.top_left.w };
-	d.bottom_left = float4{ f.bottom_left.x, f.bottom_left.y, f.bottom_left.z, f.bottom_left.w };
-	d.bottom_right = float4{ f.bottom_right.x, f.bottom_right.y, f.bottom_right.z, f.bottom_right.w };
-	return d;
-}
-
 int check_frame(const pt_frame* f) {
 	if (!f) return fail(PT_ERR_INVALID, "frame is null");
 	if (f->width <= 0 || f->height <= 0) return fail(PT_ERR_INVALID, "frame width/height must be positive");

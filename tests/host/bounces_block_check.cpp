@@ -50,15 +50,7 @@ int main(int argc, char** argv) {
 	const SceneHeader* hdr = reinterpret_cast<const SceneHeader*>(blob);
 	if (hdr->magic != kSceneMagic || hdr->blob_bytes != blob_v.size() || hdr->n_nodes != 0) { std::fprintf(stderr, "not a brute-force scene blob\n"); return 2; }
 
-	FrameDev f;      // to_dev (pt_kernels.hip)
-	f.width = fr.width; f.height = fr.height; f.pixel_first = fr.pixel_first; f.pixel_count = fr.pixel_count;
-	f.depth = fr.depth; f.seed = fr.seed; f.rng_mode = fr.rng_mode; f.stride = fr.stride; f.shading = fr.shading;
-	f.fast_div = (fr.flags & PT_FRAME_FAST_DIV) ? 1u : 0u;
-	f.rcp_width = 1.0f / (float)fr.width; f.rcp_height = 1.0f / (float)fr.height;
-	f.origin = float4{ fr.origin.x, fr.origin.y, fr.origin.z, fr.origin.w };
-	f.top_left = float4{ fr.top_left.x, fr.top_left.y, fr.top_left.z, fr.top_left.w };
-	f.bottom_left = float4{ fr.bottom_left.x, fr.bottom_left.y, fr.bottom_left.z, fr.bottom_left.w };
-	f.bottom_right = float4{ fr.bottom_right.x, fr.bottom_right.y, fr.bottom_right.z, fr.bottom_right.w };
+	const FrameDev f = to_dev(fr);
 
 	const bool sequential = fr.rng_mode == PT_RNG_SEQUENTIAL;
 	if (sequential || spp == 0) spp = 1;                                        // pt_hip_render_wavefront

@@ -41,16 +41,7 @@ int main(int argc, char** argv) {
 	if (hdr->magic != kSceneMagic || hdr->blob_bytes != blob_v.size()) { std::fprintf(stderr, "not a scene blob\n"); return 2; }
 	blockDim.x = 1;                                                            // block-cooperative staging loops cover everything
 
-	// to_dev (pt_kernels.hip)
-	FrameDev f;
-	f.width = fr.width; f.height = fr.height; f.pixel_first = fr.pixel_first; f.pixel_count = fr.pixel_count;
-	f.depth = fr.depth; f.seed = fr.seed; f.rng_mode = fr.rng_mode; f.stride = fr.stride; f.shading = fr.shading;
-	f.fast_div = (fr.flags & PT_FRAME_FAST_DIV) ? 1u : 0u;
-	f.rcp_width = 1.0f / (float)fr.width; f.rcp_height = 1.0f / (float)fr.height;
-	f.origin = float4{ fr.origin.x, fr.origin.y, fr.origin.z, fr.origin.w };
-	f.top_left = float4{ fr.top_left.x, fr.top_left.y, fr.top_left.z, fr.top_left.w };
-	f.bottom_left = float4{ fr.bottom_left.x, fr.bottom_left.y, fr.bottom_left.z, fr.bottom_left.w };
-	f.bottom_right = float4{ fr.bottom_right.x, fr.bottom_right.y, fr.bottom_right.z, fr.bottom_right.w };
+	const FrameDev f = to_dev(fr);
 
 	const uint32_t n_tris = hdr->n_tris, n_mats = hdr->n_mats;
 	const bool BVH = hdr->n_nodes != 0, STRIDED = fr.rng_mode == PT_RNG_STRIDED, extended = fr.shading == PT_SHADING_EXTENDED;
