@@ -131,3 +131,23 @@ def synthetic_scene(n_triangles, seed=0xC0FFEE, emissive_share=0.05):
                     corners.append(tuple(np.float32(c) for c in p))
                 _quad(V, T, _facing(corners, inside), mat)
     return V, T, M
+
+
+def triangle_soup(n_triangles, seed):
+    """Random triangles in front of and around the default camera: arbitrary orientations (about half of them face away
+    and are culled), sizes from slivers to a third of the view, triangles that cross the view's edges and each other,
+    all three material types.  Nothing here is axis-aligned or coplanar, unlike every other scene of this file."""
+    rng = SplitMix64(seed)
+    V, T = [], []
+    M = [(DIFFUSE, (0.8, 0.7, 0.6, 1.0)), (DIFFUSE, (0.3, 0.5, 0.9, 1.0)), (REFLECTIVE, (0.9, 0.9, 0.9, 1.0)),
+         (EMISSIVE, (6.0, 5.0, 4.0, 1.0))]
+    for _ in range(n_triangles):
+        centre = np.array([(rng.uniform() - 0.5) * 1.6, (rng.uniform() - 0.5) * 1.0, 0.4 + rng.uniform() * 1.4])
+        size = 0.02 + rng.uniform() ** 2 * 0.5
+        base = len(V)
+        for _k in range(3):
+            p = centre + (np.array([rng.uniform(), rng.uniform(), rng.uniform()]) - 0.5) * 2.0 * size
+            V.append((float(np.float32(p[0])), float(np.float32(p[1])), float(np.float32(p[2])), 1.0))
+        r = rng.uniform()
+        T.append((base, base + 1, base + 2, 3 if r < 0.15 else (2 if r < 0.25 else int(rng.uniform() * 2) % 2)))
+    return V, T, M

@@ -177,3 +177,42 @@ def test_wavefront_pass_degenerate_image_shapes(pt, oracle, tmp_path, w, h):
     ref, _, st, _ = oracle.render(oracle.params(w, h, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=35))
     img, _, rays = run_host(pt, oracle, tmp_path, scenes.default_scene(), w, h, spp, rng_mode=1, stride=35, wavefront=(2, 8))
     assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+
+
+@needs_binary
+@pytest.mark.parametrize("n_tris,seed", [(7, 1), (40, 2), (64, 3), (90, 4)])
+def test_triangle_soup(pt, oracle, tmp_path, n_tris, seed):
+    """Random triangles of arbitrary orientation and size (tests/scenes.py triangle_soup), camera moved and turned: the
+    per-pixel camera-ray culling (primary_need_mask -- one lane here, so every pixel culls for itself, the strictest
+    form) must never drop a triangle the reference's test would accept.  64 triangles: the mask's last bit; 90: no mask."""
+    V, T, M = scenes.triangle_soup(n_tris, seed)
+    cam = oracle.make_camera(position=(0.05, -0.03, -0.1, 1.0), rotation=(0.03, 0.06, -0.02, 0.995), fov=70.0)
+    w, h, spp = 96, 60, 2
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, cam=cam, depth=8, spp=spp), scene=oracle.make_scene(V, T, M))
+    img, rng, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=8, cam=cam)
+    assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
+    assert st.rays > w * h * spp + 20               # the soup is in view: some camera rays hit something diffuse and bounce
+
+
+@needs_binary
+def test_triangle_soup_many_seeds(pt, oracle, tmp_path):
+    """twenty more soups of 5..60 triangles, a different camera each, small images"""
+    for seed in range(10, 30):
+        V, T, M = scenes.triangle_soup(5 + (seed * 7) % 56, seed)
+        cam = oracle.make_camera(position=(0.02 * (seed % 5) - 0.04, 0.01 * (seed % 3), -0.05 * (seed % 4), 1.0),
+                                 rotation=(0.01 * (seed % 7) - 0.03, 0.02 * (seed % 5) - 0.04, 0.0, 1.0), fov=60.0 + seed)
+        w, h = 40 + seed, 25
+        ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, cam=cam, depth=6, spp=1), scene=oracle.make_scene(V, T, M))
+        img, rng, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, 1, depth=6, cam=cam)
+        assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays, f"seed {seed}"
+
+
+@needs_block_binary
+def test_wavefront_pass_triangle_soup(pt, oracle, tmp_path):
+    V, T, M = scenes.triangle_soup(40, 5)
+    cam = oracle.make_camera(position=(0.05, -0.03, -0.1, 1.0), rotation=(0.03, 0.06, -0.02, 0.995), fov=70.0)
+    w, h, spp, depth = 60, 37, 4, 8
+    p = oracle.params(w, h, cam=cam, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=2 + 33 * depth)
+    ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M))
+    img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, cam=cam, rng_mode=1, stride=2 + 33 * depth, wavefront=(2, 3))
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays

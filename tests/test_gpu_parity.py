@@ -70,6 +70,27 @@ def test_4k_share_of_one_rank_every_pixel(pt, oracle, name, engine):
 
 
 @pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("n_tris,seed", [(7, 1), (40, 2), (64, 3), (90, 4), (33, 21), (58, 22)])
+def test_triangle_soup(pt, oracle, name, engine, n_tris, seed):
+    """Random triangles of arbitrary orientation and size, camera moved and turned (tests/scenes.py triangle_soup): the
+    camera-ray culling (primary_need_mask, per wave of 64 pixels here) must never drop a triangle the reference's test
+    accepts; 64 triangles: the mask's last bit, 90: no mask.  Every pixel, both engines, strided batches for the wavefront."""
+    V, T, M = scenes.triangle_soup(n_tris, seed)
+    cam = dict(position=(0.05, -0.03, -0.1, 1.0), rotation=(0.03, 0.06, -0.02, 0.995), fov=70.0)
+    w, h, spp, depth = 320, 200, 4, 8
+    stride = 2 + 33 * depth
+    ref, _, st_ref, _ = oracle.render(oracle.params(w, h, cam=oracle.make_camera(**cam), depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=stride),
+                                      scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h, camera=pt.CameraData(cam["position"], cam["rotation"], cam["fov"])) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=2)
+        tr.render(spp)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, ref, f"{name} soup {n_tris}/{seed}")
+    assert st.rays == st_ref.rays
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
 @pytest.mark.parametrize("w,h", [(1, 1), (1, 7), (257, 1), (3, 1000), (255, 3), (4099, 2)])
 def test_degenerate_image_shapes(pt, oracle, name, engine, w, h):
     """one pixel, one column, one row just over a block, sizes around the 256-pixel chunk and a prime width: sequential
