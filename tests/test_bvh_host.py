@@ -74,12 +74,19 @@ def mixed_scene():
     return V, T, M + M2
 
 
-@pytest.mark.parametrize("name,n_rays,camera", [("synthetic-700", 6000, (0.0, 0.0, 0.0)), ("synthetic-1500", 6000, (0.0, 0.0, 0.0)),
+def scene_by_name(name):
+    if name == "mixed":
+        return mixed_scene()
+    kind, n = name.split("-")
+    return scenes.triangle_soup(int(n), 31) if kind == "soup" else scenes.synthetic_scene(int(n))
+
+
+@pytest.mark.parametrize("name,n_rays,camera", [("synthetic-700", 6000, (0.0, 0.0, 0.0)), ("synthetic-1500", 6000, (0.0, 0.0, 0.0)), ("soup-900", 5000, (0.0, 0.0, 0.0)),
                                                 ("synthetic-10000", 1500, (0.2, -0.1, 0.05)), ("mixed", 4000, (0.2, -0.1, 0.05))])
 def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, camera):
     if not os.path.exists(CHECK):
         pytest.skip("tests/host/bvh_host_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
-    V, T, M = mixed_scene() if name == "mixed" else scenes.synthetic_scene(int(name.split("-")[1]))
+    V, T, M = scene_by_name(name)
     blob, rays = tmp_path / "scene.blob", tmp_path / "rays.f32"
     blob.write_bytes(pack(pt, V, T, M))
     make_rays(n_rays, 7, camera).tofile(rays)
@@ -92,13 +99,13 @@ def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, cam
 
 
 @pytest.mark.parametrize("name,n_rays,lanes,first", [("synthetic-1500", 1400, 64, 0), ("synthetic-10000", 700, 64, 0), ("mixed", 1500, 64, 0),
-                                                     ("synthetic-700", 333, 37, 0), ("synthetic-2500", 1200, 64, 1)])
+                                                     ("synthetic-700", 333, 37, 0), ("synthetic-2500", 1200, 64, 1), ("soup-900", 1200, 64, 0)])
 def test_extend_stage_as_a_wave_of_host_threads(pt, tmp_path, name, n_rays, lanes, first):
     """extend_bvh_block (what k_extend<false, true> runs) with diverging rays: every queue slot gets the brute-force hit.
     37 lanes: a partial wave, a ray count that is no multiple of it.  first = 1: the bounce-0 form, rays from the camera."""
     if not os.path.exists(WAVE_CHECK):
         pytest.skip("tests/host/extend_wave_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
-    V, T, M = mixed_scene() if name == "mixed" else scenes.synthetic_scene(int(name.split("-")[1]))
+    V, T, M = scene_by_name(name)
     blob, rays = tmp_path / "scene.blob", tmp_path / "rays.f32"
     blob.write_bytes(pack(pt, V, T, M))
     camera = (0.2, -0.1, 0.05)

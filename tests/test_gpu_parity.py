@@ -91,6 +91,24 @@ def test_triangle_soup(pt, oracle, name, engine, n_tris, seed):
 
 
 @pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("n_tris,seed", [(900, 31), (3000, 32)])
+def test_triangle_soup_through_the_bvh(pt, oracle, name, engine, n_tris, seed):
+    """the same kind of scene above the BVH threshold: triangles of every orientation, from slivers to a third of the view,
+    crossing each other -- boxes with large error inflations next to tight ones; every pixel against the (brute-force) oracle"""
+    V, T, M = scenes.triangle_soup(n_tris, seed)
+    cam = dict(position=(0.05, -0.03, -0.1, 1.0), rotation=(0.03, 0.06, -0.02, 0.995), fov=70.0)
+    w, h, spp, depth = 160, 100, 2, 8
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, cam=oracle.make_camera(**cam), depth=depth, spp=spp), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h, camera=pt.CameraData(cam["position"], cam["rotation"], cam["fov"])) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine, depth=depth)
+        tr.render(spp)
+        img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+    assert_bit_equal(img, ref, f"{name} BVH soup {n_tris}")
+    assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
 @pytest.mark.parametrize("w,h", [(1, 1), (1, 7), (257, 1), (3, 1000), (255, 3), (4099, 2)])
 def test_degenerate_image_shapes(pt, oracle, name, engine, w, h):
     """one pixel, one column, one row just over a block, sizes around the 256-pixel chunk and a prime width: sequential
