@@ -292,24 +292,13 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 	if (threadIdx.x == 0) count_out[blockIdx.x] = s_out;
 }
 
-// pass_mat[0] = step^(frame_first*stride), pass_mat[1] = step^stride (exponents mod 2^32-1): what a pass needs to walk
-// a pixel's strided streams sample by sample.  Two blocks of 32 lanes.
-__global__ void k_pass_matrices(uint32_t frame_first, uint32_t stride, uint32_t* __restrict__ pass_mat) {
-	uint32_t b = threadIdx.x;
-	unsigned long long k = (blockIdx.x == 0 ? (unsigned long long)frame_first * stride : (unsigned long long)stride) % 0xFFFFFFFFull;
-	uint32_t x = 1u << b;
-	for (int j = 0; k; j++, k >>= 1)
-		if (k & 1u) x = mat_apply(g_jump.cols[j], x);
-	pass_mat[32u * blockIdx.x + b] = x;
-}
-
 // One pass of an LDS-resident scene in ONE launch: stages the block's LDS, then bounces_block (pt_wavefront.hpp).
 __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                        float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
                                                        float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
-                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ ray_counts, uint32_t capacity,
+                                                       uint32_t* __restrict__ ray_counts, uint32_t capacity,
                                                        float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out,
-                                                       const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
+                                                       JumpMat pass_first, JumpMat per_sample, const uint32_t* __restrict__ rng_in,
                                                        uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending,
                                                        unsigned long long* __restrict__ need_masks, uint32_t need_masks_valid) {
 	extern __shared__ float4 s_scene[];
@@ -318,7 +307,16 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	__shared__ uint32_t s_out, s_traced;
 	stage_jump31(s_jump);
 	const bool strided = f.rng_mode == PT_RNG_STRIDED;
-	if (strided) build_stride_table(pass_mat + 32, s_stride);
+	// STRIDED: step^(frame_first*stride), the start of the pass's first sample, and step^stride, from sample to sample
+	// (host_jump_matrix).  Both go through LDS: as kernel arguments they would sit in 64 SGPRs for the whole kernel
+	// (measured: 104 spilled SGPRs and 5 % of the pass).
+	__shared__ uint32_t s_first[32], s_per[32];
+	if (strided) {
+		if (threadIdx.x < 32) { s_first[threadIdx.x] = pass_first.cols[threadIdx.x]; s_per[threadIdx.x] = per_sample.cols[threadIdx.x]; }
+		__syncthreads();
+		build_stride_table(s_per, s_stride);
+	}
+	const uint32_t* pass_mat = s_first;
 	const bool det_bounded = scene_det_bounded(scene);
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const float4* g_mats = g_tris + (size_t)n_tris * 4;
@@ -330,7 +328,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
 	__syncthreads();
 	ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
-	bounces_block(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, counts, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending, need_masks, need_masks_valid != 0u);
+	bounces_block(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending, need_masks, need_masks_valid != 0u);
 }
 
 // a10. One thread per pixel, the pass's samples folded in order.
@@ -925,21 +923,32 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	// queue blocks: fixed for every stage of every pass
 	const uint32_t G = (uint32_t)(fuse ? grid_for_pass(frame->pixel_count) : grid_for(paths_cap));
 	const uint32_t slots = (uint32_t)queue_capacity(frame->pixel_count, samples_per_pass);
+	if (fuse && stats && (uint64_t)(slots / G / samples_per_pass) * n_samples > 0xFFFFFFFFull)
+		return fail(PT_ERR_LIMIT, "render_wavefront: more samples in one call than the 32-bit ray counters of a block hold");
 
 	for (uint32_t done = 0; done < n_samples; done += samples_per_pass) {
 		uint32_t ns = std::min(samples_per_pass, n_samples - done);
 		uint32_t paths = ns * frame->pixel_count;
 		if (fuse) {
 			// LDS-resident scene: ONE launch per pass -- camera rays, every bounce (paths whose next hit is terminal are
-			// finished by their producer: lit flags start at zero, rays are counted apart from the queue) and the fold
-			// into the mean; queue slots and pixels are block-private, so no stage waits for another block
-			HIP_TRY(hipMemsetAsync(w.lit, 0, paths, s));
-			if (!sequential) hipLaunchKernelGGL(k_pass_matrices, dim3(2), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
+			// finished by their producer, rays are counted apart from the queue) and the fold into the mean; queue slots
+			// and pixels are block-private, so no stage waits for another block.  Nothing else is launched per pass: the
+			// jump matrices come from the host, the flags of waiting samples are written where the samples are made, and
+			// the ray counters add up in place until the call's last pass
+			JumpMat first{}, per{};
+			if (!sequential) {
+				host_jump_matrix((uint64_t)(frame_first + done) * frame->stride, first.cols);
+				host_jump_matrix(frame->stride, per.cols);
+			}
+			if (done == 0 && stats) HIP_TRY(hipMemsetAsync(w.ray_counts, 0, (size_t)(frame->depth + 1) * G * sizeof(uint32_t), s));
 			size_t lds_bytes = shade_lds_bytes(si) + (size_t)si.n_tris * sizeof(PrimRec);
 			hipLaunchKernelGGL(k_bounces, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats,
 			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1],
-			                   w.counts, w.ray_counts, slots, w.radiance, w.lit, sequential ? rng : nullptr,
-			                   (const uint32_t*)w.smat, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending, w.need_masks, done != 0u ? 1u : 0u);
+			                   w.ray_counts, slots, w.radiance, w.lit, sequential ? rng : nullptr,
+			                   first, per, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending, w.need_masks, done != 0u ? 1u : 0u);
+			// uint32 counters: fold before a block's share of a bounce can pass 2^32 rays (it owns at most `slots / G / ns` pixels)
+			bool last_pass = done + samples_per_pass >= n_samples;
+			if (stats && last_pass) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.ray_counts, G, frame->depth, (unsigned long long*)stats);
 		} else {
 			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
 			if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
@@ -953,7 +962,7 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 			hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
 			                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
 		}
-		if (stats) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)(fuse ? w.ray_counts : w.counts), G, frame->depth, (unsigned long long*)stats);
+		if (stats && !fuse) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.counts, G, frame->depth, (unsigned long long*)stats);
 		HIP_TRY(hipGetLastError());
 	}
 	return PT_OK;

@@ -48,7 +48,7 @@ struct PathNext {
 // One lane, one path: the hit h of slot q is shaded (kernels.cu:44-96).  GEN: the camera ray was made by the caller
 // (gen_b = direction + rng word) and no queue is read.  RESOLVE (needs EXTEND): the continuing ray's hit is known right
 // here, so a path whose next hit is terminal -- nothing, an emitter, or (REFERENCE shading) an absorber -- is finished by
-// its producer and never enters the queue; `lit` must then be zero when the pass starts (a finished path writes only if
+// its producer and never enters the queue; `lit` must then be zero for every queued path (a finished path writes only if
 // it reached an emitter).
 // DEFER: a path that ends here stores nothing; the caller gets done / emitted / frame and decides (bounces_block folds
 // them into the mean straight from registers while the pixel's samples are still in order).
@@ -213,13 +213,14 @@ __device__ __forceinline__ void build_stride_table(const uint32_t* __restrict__ 
 // 4 LDS lookups) from that of sample s instead of a 32-column matrix product per path; the bounce-0 queue is never
 // materialised.  Terminal next hits are resolved by their producer (RESOLVE).  After the last bounce the block folds
 // its pixels' samples into the running mean in sample order (a10) -- no separate accumulate launch, and the flags and
-// radiances it reads are still in its L1/L2.  The per-bounce counters are still written, for the statistics.
+// radiances it reads are still in its L1/L2.  The per-bounce ray counters add up over the passes of a render call, for the
+// statistics (zeroed by the caller before the first pass, folded after the last).
 // On entry the block's copies of the scene (tris, mats, camera-ray records), the step^31 and step^stride tables are staged,
 // *c.s_out = *c.s_traced = 0 and a block barrier has been passed.
 __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* __restrict__ s_prim, const uint32_t* __restrict__ s_stride,
                                               float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
                                               float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
-                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ ray_counts,
+                                              uint32_t* __restrict__ ray_counts,
                                               const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
                                               uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending,
                                               unsigned long long* __restrict__ need_masks, bool need_masks_valid) {
@@ -245,7 +246,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 			uint32_t i = f.pixel_first + (active ? li : 0u);
 			uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
 			uint32_t r0 = active ? rng_in[li] : 0u;
-			if (strided) r0 = mat_apply(pass_mat, r0);         // start of the pass's first sample
+			if (strided) r0 = mat_apply_lds(pass_mat, r0);     // start of the pass's first sample (once per pixel: rolled LDS reads)
 			// The running mean is order-dependent, so a sample's frame can be folded here, from registers, only while
 			// every earlier sample of the pixel has been: fp = the first sample that went into the queue (n_samples: none).
 			// From fp on, finished samples leave their flag / radiance in memory and the fold at the end takes over.
@@ -276,7 +277,10 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 					if (r.done && fp == n_samples) m = running_mean(r.frame, m, mean_first + s);
 					else {
 						if (fp == n_samples) fp = s;
-						if (r.done && r.emitted) { lit[r.pid] = 1; radiance[r.pid] = r.frame; }      // lit starts at zero
+						// a sample that waits for the fold leaves its flag here: set if it ended on a light, clear if it ended
+						// otherwise or goes on (a later bounce sets it when the path reaches a light: RESOLVE writes nothing else)
+						lit[r.pid] = r.done && r.emitted ? 1 : 0;
+						if (r.done && r.emitted) radiance[r.pid] = r.frame;
 					}
 					if (r.done && c.rng_out) c.rng_out[r.pid] = r.rng;   // SEQUENTIAL: one sample per pass, pid = local pixel
 				}
@@ -285,7 +289,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 			if (traced_acc && (threadIdx.x & 63u) == 0u) atomicAdd(c.s_traced, traced_acc);
 			if (active) { mean[li] = m; first_pending[li] = fp; }
 		}
-		if (threadIdx.x == 0) { counts[blockIdx.x] = owned * n_samples; ray_counts[blockIdx.x] = owned * n_samples; }
+		if (threadIdx.x == 0) ray_counts[blockIdx.x] += owned * n_samples;      // the counters add up over the passes of a call
 	}
 	for (uint32_t b = 1;; b++) {
 		__syncthreads();
@@ -293,17 +297,12 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 		uint32_t traced = s_traced;
 		__syncthreads();
 		if (threadIdx.x == 0) {
-			counts[(size_t)b * G + blockIdx.x] = count;
-			ray_counts[(size_t)b * G + blockIdx.x] = traced;
+			ray_counts[(size_t)b * G + blockIdx.x] += traced;
 			s_out = 0; s_traced = 0;
 		}
 		__syncthreads();
 		if (b >= f.depth) break;
-		if (count == 0) {                                       // nothing left: the remaining rows are zero
-			if (threadIdx.x == 0)
-				for (uint32_t r = b + 1; r <= f.depth; r++) { counts[(size_t)r * G + blockIdx.x] = 0; ray_counts[(size_t)r * G + blockIdx.x] = 0; }
-			break;
-		}
+		if (count == 0) break;                                  // nothing left: the remaining rows get nothing added
 		uint32_t last = b + 1 >= f.depth ? 1u : 0u;
 		if (b & 1u) shade_block<false, true, true>(c, last, count, a1, b1, c1, pid1, hit1, a0, b0, c0, pid0, hit0);
 		else shade_block<false, true, true>(c, last, count, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1);

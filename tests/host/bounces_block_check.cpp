@@ -64,8 +64,8 @@ int main(int argc, char** argv) {
 	for (int k = 0; k < 2; k++) { qa[k] = exact<float4>(slots); qb[k] = exact<float4>(slots); qc[k] = exact<float4>(slots); qpid[k] = exact<uint32_t>(slots); qhit[k] = exact<uint2>(slots); }
 	float4* radiance = exact<float4>(paths_cap);
 	unsigned char* lit = exact<unsigned char>(paths_cap);
-	uint32_t* counts = exact<uint32_t>((size_t)(f.depth + 1) * G);
 	uint32_t* ray_counts = exact<uint32_t>((size_t)(f.depth + 1) * G);
+	std::memset(ray_counts, 0, (size_t)(f.depth + 1) * G * sizeof(uint32_t));      // the library zeroes them before a call's first pass
 	uint32_t* pass_mat = exact<uint32_t>(64);
 	float4* mean = exact<float4>(N);
 	uint32_t* rng = exact<uint32_t>(N);
@@ -88,7 +88,6 @@ int main(int argc, char** argv) {
 	gridDim.x = G;
 	for (uint32_t done = 0; done < n_samples; done += spp) {
 		const uint32_t ns = std::min(spp, n_samples - done);
-		std::memset(lit, 0, (size_t)ns * N);
 		if (!sequential)                                                        // k_pass_matrices
 			for (uint32_t b = 0; b < 32; b++) {
 				pass_mat[b] = steps(1u << b, (unsigned long long)(frame_first + done) * f.stride);
@@ -115,13 +114,13 @@ int main(int argc, char** argv) {
 					__syncthreads();
 					ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, (uint32_t)slots, radiance, lit, sequential ? rng : nullptr, &s_out, &s_traced };
 					bounces_block(c, s_scene + nt4 + nm2, s_stride, qa[0], qb[0], qc[0], qpid[0], qhit[0], qa[1], qb[1], qc[1], qpid[1], qhit[1],
-					              counts, ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0);
+					              ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0);
 				});
 			for (auto& t : th) t.join();
 		}
-		for (uint32_t b = 0; b < f.depth; b++)                                     // k_fold_counts, stats[0]
-			for (uint32_t blk = 0; blk < G; blk++) rays += ray_counts[(size_t)b * G + blk];
 	}
+	for (uint32_t b = 0; b < f.depth; b++)                                         // k_fold_counts, stats[0], after the last pass
+		for (uint32_t blk = 0; blk < G; blk++) rays += ray_counts[(size_t)b * G + blk];
 	FILE* out = std::fopen(argv[7], "wb");
 	if (!out) { std::perror(argv[7]); return 2; }
 	std::fwrite(mean, sizeof(float4), N, out);
