@@ -197,7 +197,11 @@ int pt_hip_accumulate(uint32_t pixel_count, uint32_t mean_first, uint32_t n_samp
 /* a11: the kernel sequence of PathTracer::BeginDrawing (PathTracer.cu:116-157) for n_samples
  * samples, no host synchronisation inside.  frame_first = RNG sample index of the first sample
  * (STRIDED), mean_first = samples already in `mean` (the reference's frameNumber).
- * workspace: pt_hip_wavefront_workspace_bytes(pixel_count, samples_per_pass, depth) bytes. */
+ * workspace: pt_hip_wavefront_workspace_bytes(pixel_count, samples_per_pass, depth) bytes.
+ * samples_per_pass: STRIDED, samples of a pixel in flight together (the queues hold pixel_count x
+ * samples_per_pass paths).  SEQUENTIAL, a pixel's samples follow one another whatever its value
+ * (one in flight, queues of pixel_count paths): on a scene that fits LDS it is the number of
+ * samples one launch works through in rounds, on a BVH scene every sample is a pass of its own. */
 size_t pt_hip_wavefront_workspace_bytes(uint32_t pixel_count, uint32_t samples_per_pass, uint32_t depth);
 int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                             uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,

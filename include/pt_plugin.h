@@ -44,7 +44,7 @@ typedef struct {
     uint32_t depth;              /* bounce iterations, default 10 (PathTracer.cu:129) */
     uint32_t seed;               /* default 1337 (kernels.cu:29) */
     uint32_t samples_per_begin;  /* samples one BeginDrawing adds, default 1 (the reference) */
-    uint32_t samples_per_pass;   /* wavefront + STRIDED: samples batched per pass, default 16 */
+    uint32_t samples_per_pass;   /* wavefront: samples per pass, default 16 (STRIDED: in flight together; SEQUENTIAL: per launch, in rounds) */
     int32_t  device;             /* HIP device ordinal, default: the current device */
     uint32_t pixel_first;        /* tile split: first pixel index rendered by this instance */
     uint32_t pixel_count;        /* 0 = the whole image */

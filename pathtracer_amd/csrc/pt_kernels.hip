@@ -293,6 +293,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 }
 
 // One pass of an LDS-resident scene in ONE launch: stages the block's LDS, then bounces_block (pt_wavefront.hpp).
+template <bool SEQ>
 __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                        float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
                                                        float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
@@ -304,9 +305,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_stride[1024];       // STRIDED: byte tables of step^stride
-	__shared__ uint32_t s_out, s_traced;
+	__shared__ uint32_t s_out, s_traced, s_round[2];
 	stage_jump31(s_jump);
-	const bool strided = f.rng_mode == PT_RNG_STRIDED;
+	const bool strided = !SEQ;
 	// STRIDED: step^(frame_first*stride), the start of the pass's first sample, and step^stride, from sample to sample
 	// (host_jump_matrix).  Both go through LDS: as kernel arguments they would sit in 64 SGPRs for the whole kernel
 	// (measured: 104 spilled SGPRs and 5 % of the pass).
@@ -325,10 +326,10 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	for (uint32_t k = threadIdx.x; k < nm2; k += kBlock) s_scene[nt4 + k] = g_mats[k];
 	const float4* s_prim = s_scene + nt4 + nm2;
 	stage_primary_records(g_tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_scene + nt4 + nm2);
-	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
+	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; s_round[0] = 0; s_round[1] = 0; }
 	__syncthreads();
 	ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
-	bounces_block(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending, need_masks, need_masks_valid != 0u);
+	bounces_block<SEQ>(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending, need_masks, need_masks_valid != 0u, s_round);
 }
 
 // a10. One thread per pixel, the pass's samples folded in order.
@@ -906,9 +907,12 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	if (int rc = check_frame(frame)) return rc;
 	if (!scene_blob || !rng || !mean || !workspace) return fail(PT_ERR_INVALID, "render_wavefront: null pointer");
 	if (n_samples == 0 || frame->pixel_count == 0) return PT_OK;
-	if (frame->rng_mode == PT_RNG_SEQUENTIAL) samples_per_pass = 1;
 	if (samples_per_pass == 0) samples_per_pass = 1;
 	samples_per_pass = std::min(samples_per_pass, n_samples);
+	// SEQUENTIAL: a pixel's samples follow one another, one is in flight at a time and the queues are sized for that;
+	// the one-launch pass still takes `per_launch` of them in a row (bounces_block<true>), the staged one a single sample
+	uint32_t per_launch = samples_per_pass;
+	if (frame->rng_mode == PT_RNG_SEQUENTIAL) samples_per_pass = 1;
 	if (queue_capacity(frame->pixel_count, samples_per_pass) > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "render_wavefront: more than 2^32-1 queue slots per pass");
 	size_t paths_cap = (size_t)frame->pixel_count * samples_per_pass;
 	Workspace w;
@@ -920,14 +924,16 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	const bool sequential = frame->rng_mode == PT_RNG_SEQUENTIAL;
 	// scene resident in LDS: the whole pass is one launch (k_bounces)
 	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si);
+	if (!fuse) per_launch = samples_per_pass;
+	per_launch = std::min(per_launch, 0x7FFFFFFFu);          // bounces_block<true> keeps a flag in the sample index's top bit
 	// queue blocks: fixed for every stage of every pass
 	const uint32_t G = (uint32_t)(fuse ? grid_for_pass(frame->pixel_count) : grid_for(paths_cap));
 	const uint32_t slots = (uint32_t)queue_capacity(frame->pixel_count, samples_per_pass);
 	if (fuse && stats && (uint64_t)(slots / G / samples_per_pass) * n_samples > 0xFFFFFFFFull)
 		return fail(PT_ERR_LIMIT, "render_wavefront: more samples in one call than the 32-bit ray counters of a block hold");
 
-	for (uint32_t done = 0; done < n_samples; done += samples_per_pass) {
-		uint32_t ns = std::min(samples_per_pass, n_samples - done);
+	for (uint32_t done = 0; done < n_samples; done += per_launch) {
+		uint32_t ns = std::min(per_launch, n_samples - done);
 		uint32_t paths = ns * frame->pixel_count;
 		if (fuse) {
 			// LDS-resident scene: ONE launch per pass -- camera rays, every bounce (paths whose next hit is terminal are
@@ -942,12 +948,14 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 			}
 			if (done == 0 && stats) HIP_TRY(hipMemsetAsync(w.ray_counts, 0, (size_t)(frame->depth + 1) * G * sizeof(uint32_t), s));
 			size_t lds_bytes = shade_lds_bytes(si) + (size_t)si.n_tris * sizeof(PrimRec);
-			hipLaunchKernelGGL(k_bounces, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats,
-			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1],
-			                   w.ray_counts, slots, w.radiance, w.lit, sequential ? rng : nullptr,
-			                   first, per, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending, w.need_masks, done != 0u ? 1u : 0u);
+#define PT_BOUNCES(SEQ) hipLaunchKernelGGL(k_bounces<SEQ>, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, \
+			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1], \
+			                   w.ray_counts, slots, w.radiance, w.lit, SEQ ? rng : nullptr, \
+			                   first, per, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending, w.need_masks, done != 0u ? 1u : 0u)
+			if (sequential) PT_BOUNCES(true); else PT_BOUNCES(false);
+#undef PT_BOUNCES
 			// uint32 counters: fold before a block's share of a bounce can pass 2^32 rays (it owns at most `slots / G / ns` pixels)
-			bool last_pass = done + samples_per_pass >= n_samples;
+			bool last_pass = done + per_launch >= n_samples;
 			if (stats && last_pass) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.ray_counts, G, frame->depth, (unsigned long long*)stats);
 		} else {
 			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);

@@ -217,17 +217,22 @@ __device__ __forceinline__ void build_stride_table(const uint32_t* __restrict__ 
 // statistics (zeroed by the caller before the first pass, folded after the last).
 // On entry the block's copies of the scene (tris, mats, camera-ray records), the step^31 and step^stride tables are staged,
 // *c.s_out = *c.s_traced = 0 and a block barrier has been passed.
+constexpr uint32_t kSeqQueued = 0x80000000u;
+#ifndef PT_SEQ_QUORUM_NUM
+#define PT_SEQ_QUORUM_NUM 1u
+#define PT_SEQ_QUORUM_DEN 2u
+#endif
+template <bool SEQ>
 __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* __restrict__ s_prim, const uint32_t* __restrict__ s_stride,
                                               float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
                                               float4* __restrict__ a1, float4* __restrict__ b1, float4* __restrict__ c1, uint32_t* __restrict__ pid1, uint2* __restrict__ hit1,
                                               uint32_t* __restrict__ ray_counts,
                                               const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
                                               uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending,
-                                              unsigned long long* __restrict__ need_masks, bool need_masks_valid) {
+                                              unsigned long long* __restrict__ need_masks, bool need_masks_valid, uint32_t* s_round) {
 	const FrameDev& f = c.f;
 	const uint32_t n_tris = c.n_tris;
 	const bool det_bounded = c.det_bounded;
-	const bool strided = f.rng_mode == PT_RNG_STRIDED;
 	uint32_t& s_out = *c.s_out;
 	uint32_t& s_traced = *c.s_traced;
 	float4* __restrict__ radiance = c.radiance;
@@ -235,91 +240,171 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 	const uint32_t G = gridDim.x;
 	const bool extended = f.shading == PT_SHADING_EXTENDED;
 
-	// bounce 0
-	{
-		const uint32_t last = f.depth <= 1u ? 1u : 0u;
-		uint32_t owned = 0;
-		for (uint32_t li0 = blockIdx.x * kQueueBlock; li0 < f.pixel_count; li0 += G * kQueueBlock) {
-			uint32_t li = li0 + threadIdx.x;
-			bool active = li < f.pixel_count;
-			owned += min(kQueueBlock, f.pixel_count - li0);
-			uint32_t i = f.pixel_first + (active ? li : 0u);
-			uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
-			uint32_t r0 = active ? rng_in[li] : 0u;
-			if (strided) r0 = mat_apply_lds(pass_mat, r0);     // start of the pass's first sample (once per pixel: rolled LDS reads)
-			// The running mean is order-dependent, so a sample's frame can be folded here, from registers, only while
-			// every earlier sample of the pixel has been: fp = the first sample that went into the queue (n_samples: none).
-			// From fp on, finished samples leave their flag / radiance in memory and the fold at the end takes over.
-			float4 m = active ? mean[li] : float4{ 0, 0, 0, 0 };
-			uint32_t fp = n_samples;
-			uint32_t traced_acc = 0;                            // wave-uniform: rays this wave traced for bounce 1 in this chunk
-			// which triangles this wave's 64 pixels can see: worked out in the first pass of a render call, kept per wave
-			// (one word per 64 pixels) for the passes that follow -- it depends on the pixels and the camera only
-			unsigned long long need;
-			const uint32_t wave_slot = li0 / 64u + (threadIdx.x >> 6);
-			if (need_masks_valid) need = need_masks[wave_slot];
-			else {
-				need = primary_need_mask(f, px, py, active, c.tris, s_prim, n_tris);                       // every lane of the block is here
-				if ((threadIdx.x & 63u) == 0u) need_masks[wave_slot] = need;
-			}
-			for (uint32_t s = 0; s < n_samples; s++) {
-				if (strided && s) r0 = byte_jump(s_stride, r0);
-				PathNext r;
-				r.pid = s * f.pixel_count + li;
-				if (active) {
-					uint32_t rs = r0;                               // r0 stays the start of this sample's stream
-					Vec3 gd = primary_direction(f, px, py, rs);
-					float best = FLT_MAX;
-					uint32_t ptri = kNoHit;
-					intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri, need);
-					shade_lane<true, true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
-					                                        float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
-					if (r.done && fp == n_samples) m = running_mean(r.frame, m, mean_first + s);
-					else {
-						if (fp == n_samples) fp = s;
-						// a sample that waits for the fold leaves its flag here: set if it ended on a light, clear if it ended
-						// otherwise or goes on (a later bounce sets it when the path reaches a light: RESOLVE writes nothing else)
-						lit[r.pid] = r.done && r.emitted ? 1 : 0;
-						if (r.done && r.emitted) radiance[r.pid] = r.frame;
-					}
-					if (r.done && c.rng_out) c.rng_out[r.pid] = r.rng;   // SEQUENTIAL: one sample per pass, pid = local pixel
+	for (bool first_round = true;; first_round = false) {
+		// bounce 0
+		{
+			const uint32_t last = f.depth <= 1u ? 1u : 0u;
+			uint32_t owned = 0;
+			for (uint32_t li0 = blockIdx.x * kQueueBlock; li0 < f.pixel_count; li0 += G * kQueueBlock) {
+				uint32_t li = li0 + threadIdx.x;
+				bool active = li < f.pixel_count;
+				owned += min(kQueueBlock, f.pixel_count - li0);
+				uint32_t i = f.pixel_first + (active ? li : 0u);
+				uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
+				uint32_t traced_acc = 0;                            // wave-uniform: rays this wave traced for bounce 1 in this chunk
+				// which triangles this wave's 64 pixels can see: worked out in the first pass of a render call, kept per wave
+				// (one word per 64 pixels) for the passes that follow -- it depends on the pixels and the camera only
+				unsigned long long need;
+				const uint32_t wave_slot = li0 / 64u + (threadIdx.x >> 6);
+				if (need_masks_valid || !first_round) need = need_masks[wave_slot];
+				else {
+					need = primary_need_mask(f, px, py, active, c.tris, s_prim, n_tris);                       // every lane of the block is here
+					if ((threadIdx.x & 63u) == 0u) need_masks[wave_slot] = need;
 				}
-				queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1, &traced_acc);
+				if (SEQ) {
+					// SEQUENTIAL streams: sample s+1 of a pixel starts where sample s stopped, so a lane makes its pixel's samples
+					// one after the other for as long as each ends right here (its frame goes into the mean from registers, its
+					// last rng word starts the next), and stops at the first that goes into the queue: that one is alone in
+					// flight for its pixel (pid = the local pixel, as with one sample per pass), the bounce loop below finishes
+					// it and leaves the stream's word in rng_out, the fold takes its frame, and the next round goes on from
+					// there.  first_pending = the pixel's next sample, with kSeqQueued set while that sample is in the queue.
+					uint32_t s = !active ? n_samples : first_round ? 0u : first_pending[li];
+					bool go = s < n_samples, queued = false;
+					const bool had = go;
+					float4 m = float4{ 0, 0, 0, 0 };
+					uint32_t r0 = 0;
+					if (go) { m = mean[li]; r0 = c.rng_out[li]; }
+					uint32_t made = 0;                                // wave-uniform: camera rays this wave made in this chunk
+					const uint32_t started = (uint32_t)__popcll(__ballot(go));
+					for (;;) {
+						// the wave goes on while enough of the lanes that started this round still make samples: the others wait
+						// for their queued sample, and a wave that ran on for a few lanes would issue mostly idle instructions
+						// (the lanes left over simply go on in the next round)
+						uint32_t going = (uint32_t)__popcll(__ballot(go));
+						if (going == 0u || going * PT_SEQ_QUORUM_DEN < started * PT_SEQ_QUORUM_NUM) break;
+						made += going;
+						PathNext r;
+						r.pid = li;
+						if (go) {
+							uint32_t rs = r0;
+							Vec3 gd = primary_direction(f, px, py, rs);
+							float best = FLT_MAX;
+							uint32_t ptri = kNoHit;
+							intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri, need);
+							shade_lane<true, true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
+							                                        float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
+							if (r.done) {
+								m = running_mean(r.frame, m, mean_first + s);
+								r0 = r.rng;
+								s++;
+								go = s < n_samples;
+							} else {
+								lit[li] = 0;                                   // a later bounce sets it if the path reaches a light
+								go = false;
+								queued = true;
+							}
+						}
+						queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1, &traced_acc);
+					}
+					if ((threadIdx.x & 63u) == 0u) {
+						if (traced_acc) atomicAdd(c.s_traced, traced_acc);
+						if (made) atomicAdd(&s_round[1], made);
+					}
+					if (had) {
+						mean[li] = m;
+						first_pending[li] = s | (queued ? kSeqQueued : 0u);
+						if (!queued) c.rng_out[li] = r0;                 // a queued sample's path writes the word when it ends
+					}
+				} else {
+					uint32_t r0 = active ? rng_in[li] : 0u;
+					r0 = mat_apply_lds(pass_mat, r0);                  // start of the pass's first sample (once per pixel: rolled LDS reads)
+					// The running mean is order-dependent, so a sample's frame can be folded here, from registers, only while
+					// every earlier sample of the pixel has been: fp = the first sample that went into the queue (n_samples: none).
+					// From fp on, finished samples leave their flag / radiance in memory and the fold at the end takes over.
+					float4 m = active ? mean[li] : float4{ 0, 0, 0, 0 };
+					uint32_t fp = n_samples;
+					for (uint32_t s = 0; s < n_samples; s++) {
+						if (s) r0 = byte_jump(s_stride, r0);
+						PathNext r;
+						r.pid = s * f.pixel_count + li;
+						if (active) {
+							uint32_t rs = r0;                               // r0 stays the start of this sample's stream
+							Vec3 gd = primary_direction(f, px, py, rs);
+							float best = FLT_MAX;
+							uint32_t ptri = kNoHit;
+							intersect_range_primary(c.tris, s_prim, n_tris, det_bounded, gd, best, ptri, need);
+							shade_lane<true, true, true, true, true>(c, extended, last, 0u, uint2{ __float_as_uint(best), ptri },
+							                                        float4{ gd.x, gd.y, gd.z, __uint_as_float(rs) }, nullptr, nullptr, nullptr, r);
+							if (r.done && fp == n_samples) m = running_mean(r.frame, m, mean_first + s);
+							else {
+								if (fp == n_samples) fp = s;
+								// a sample that waits for the fold leaves its flag here: set if it ended on a light, clear if it ended
+								// otherwise or goes on (a later bounce sets it when the path reaches a light: RESOLVE writes nothing else)
+								lit[r.pid] = r.done && r.emitted ? 1 : 0;
+								if (r.done && r.emitted) radiance[r.pid] = r.frame;
+							}
+						}
+						queue_push<true, true>(c, last, r, a1, b1, c1, pid1, hit1, &traced_acc);
+					}
+					if (traced_acc && (threadIdx.x & 63u) == 0u) atomicAdd(c.s_traced, traced_acc);
+					if (active) { mean[li] = m; first_pending[li] = fp; }
+				}
 			}
-			if (traced_acc && (threadIdx.x & 63u) == 0u) atomicAdd(c.s_traced, traced_acc);
-			if (active) { mean[li] = m; first_pending[li] = fp; }
+			if (!SEQ && threadIdx.x == 0) ray_counts[blockIdx.x] += owned * n_samples;      // the counters add up over the passes of a call
 		}
-		if (threadIdx.x == 0) ray_counts[blockIdx.x] += owned * n_samples;      // the counters add up over the passes of a call
-	}
-	for (uint32_t b = 1;; b++) {
-		__syncthreads();
-		uint32_t count = s_out;
-		uint32_t traced = s_traced;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			ray_counts[(size_t)b * G + blockIdx.x] += traced;
-			s_out = 0; s_traced = 0;
+		for (uint32_t b = 1;; b++) {
+			__syncthreads();
+			uint32_t count = s_out;
+			uint32_t traced = s_traced;
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				ray_counts[(size_t)b * G + blockIdx.x] += traced;
+				s_out = 0; s_traced = 0;
+				if (SEQ && b == 1u) { ray_counts[blockIdx.x] += s_round[1]; s_round[1] = 0; }
+			}
+			__syncthreads();
+			if (b >= f.depth) break;
+			if (count == 0) break;                                  // nothing left: the remaining rows get nothing added
+			uint32_t last = b + 1 >= f.depth ? 1u : 0u;
+			if (b & 1u) shade_block<false, true, true>(c, last, count, a1, b1, c1, pid1, hit1, a0, b0, c0, pid0, hit0);
+			else shade_block<false, true, true>(c, last, count, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1);
 		}
+		// a10: this block's pixels, the waiting samples folded in order
 		__syncthreads();
-		if (b >= f.depth) break;
-		if (count == 0) break;                                  // nothing left: the remaining rows get nothing added
-		uint32_t last = b + 1 >= f.depth ? 1u : 0u;
-		if (b & 1u) shade_block<false, true, true>(c, last, count, a1, b1, c1, pid1, hit1, a0, b0, c0, pid0, hit0);
-		else shade_block<false, true, true>(c, last, count, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1);
-	}
-	// a10: this block's pixels, the pass's samples folded in order
-	__syncthreads();
-	for (uint32_t li = blockIdx.x * kQueueBlock + threadIdx.x; li < f.pixel_count; li += G * kQueueBlock) {
-		uint32_t fp = first_pending[li];
-		if (fp >= n_samples) continue;                             // every sample was folded where it was made
-		float4 m = mean[li];
-		for (uint32_t s = fp; s < n_samples; s++) {
-			size_t p = (size_t)s * f.pixel_count + li;
-			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };        // kernels.cu:49
-			if (lit[p]) frame = radiance[p];
-			m = running_mean(frame, m, mean_first + s);
+		if (SEQ) {
+			bool more = false;
+			for (uint32_t li = blockIdx.x * kQueueBlock + threadIdx.x; li < f.pixel_count; li += G * kQueueBlock) {
+				uint32_t s = first_pending[li];
+				if (s & kSeqQueued) {                                   // the queued sample has ended by now: its frame is next in order
+					s &= ~kSeqQueued;
+					float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };        // kernels.cu:49
+					if (lit[li]) frame = radiance[li];
+					mean[li] = running_mean(frame, mean[li], mean_first + s);
+					first_pending[li] = ++s;
+				}
+				more = more || s < n_samples;
+			}
+			if (more) s_round[0] = 1u;                               // same value from every lane that writes
+			__syncthreads();
+			uint32_t again = s_round[0];
+			__syncthreads();
+			if (again == 0u) break;
+			if (threadIdx.x == 0) s_round[0] = 0u;                   // read again only after the barriers of the next bounce loop
+		} else {
+			for (uint32_t li = blockIdx.x * kQueueBlock + threadIdx.x; li < f.pixel_count; li += G * kQueueBlock) {
+				uint32_t fp = first_pending[li];
+				if (fp >= n_samples) continue;                             // every sample was folded where it was made
+				float4 m = mean[li];
+				for (uint32_t s = fp; s < n_samples; s++) {
+					size_t p = (size_t)s * f.pixel_count + li;
+					float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };        // kernels.cu:49
+					if (lit[p]) frame = radiance[p];
+					m = running_mean(frame, m, mean_first + s);
+				}
+				mean[li] = m;
+			}
+			break;
 		}
-		mean[li] = m;
 	}
 }
 

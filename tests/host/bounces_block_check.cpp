@@ -53,8 +53,10 @@ int main(int argc, char** argv) {
 	const FrameDev f = to_dev(fr);
 
 	const bool sequential = fr.rng_mode == PT_RNG_SEQUENTIAL;
-	if (sequential || spp == 0) spp = 1;                                        // pt_hip_render_wavefront
+	if (spp == 0) spp = 1;                                                      // pt_hip_render_wavefront
 	if (spp > n_samples) spp = n_samples;
+	const uint32_t per_launch = spp;                                            // SEQUENTIAL: samples per launch, one in flight per pixel
+	if (sequential) spp = 1;
 	const uint32_t N = f.pixel_count, n_tris = hdr->n_tris, n_mats = hdr->n_mats;
 	const uint32_t chunks = (N + 255u) / 256u;
 	const uint32_t G = std::max(1u, std::min(chunks, max_blocks));             // grid_for(pixel_count) with max_blocks in place of 8 x CUs
@@ -78,7 +80,7 @@ int main(int argc, char** argv) {
 	float4* s_scene = exact<float4>((size_t)nt4 + nm2 + 2 * n_tris);
 	uint32_t* s_jump = exact<uint32_t>(1024);
 	uint32_t* s_stride = exact<uint32_t>(1024);
-	uint32_t s_out = 0, s_traced = 0;
+	uint32_t s_out = 0, s_traced = 0, s_round[2] = { 0xDBDBDBDBu, 0xDBDBDBDBu };
 	static const ByteJump jump31 = make_byte_jump(31);
 	const float4* g_tris = reinterpret_cast<const float4*>(blob + sizeof(SceneHeader));
 	const float4* g_mats = g_tris + (size_t)n_tris * 4;
@@ -86,8 +88,8 @@ int main(int argc, char** argv) {
 
 	unsigned long long rays = 0;
 	gridDim.x = G;
-	for (uint32_t done = 0; done < n_samples; done += spp) {
-		const uint32_t ns = std::min(spp, n_samples - done);
+	for (uint32_t done = 0; done < n_samples; done += per_launch) {
+		const uint32_t ns = std::min(per_launch, n_samples - done);
 		if (!sequential)                                                        // k_pass_matrices
 			for (uint32_t b = 0; b < 32; b++) {
 				pass_mat[b] = steps(1u << b, (unsigned long long)(frame_first + done) * f.stride);
@@ -110,11 +112,15 @@ int main(int argc, char** argv) {
 					for (uint32_t k = t; k < nt4; k += 256u) s_scene[k] = g_tris[k];
 					for (uint32_t k = t; k < nm2; k += 256u) s_scene[nt4 + k] = g_mats[k];
 					stage_primary_records(g_tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_scene + nt4 + nm2);
-					if (t == 0) { s_out = 0; s_traced = 0; }
+					if (t == 0) { s_out = 0; s_traced = 0; s_round[0] = 0; s_round[1] = 0; }
 					__syncthreads();
 					ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, (uint32_t)slots, radiance, lit, sequential ? rng : nullptr, &s_out, &s_traced };
-					bounces_block(c, s_scene + nt4 + nm2, s_stride, qa[0], qb[0], qc[0], qpid[0], qhit[0], qa[1], qb[1], qc[1], qpid[1], qhit[1],
-					              ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0);
+					if (sequential)
+						bounces_block<true>(c, s_scene + nt4 + nm2, s_stride, qa[0], qb[0], qc[0], qpid[0], qhit[0], qa[1], qb[1], qc[1], qpid[1], qhit[1],
+						                    ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0, s_round);
+					else
+						bounces_block<false>(c, s_scene + nt4 + nm2, s_stride, qa[0], qb[0], qc[0], qpid[0], qhit[0], qa[1], qb[1], qc[1], qpid[1], qhit[1],
+						                     ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0, s_round);
 				});
 			for (auto& t : th) t.join();
 		}

@@ -134,6 +134,34 @@ def test_wavefront_pass_default_scene(pt, oracle, tmp_path, w, h, spp, per_pass,
 
 
 @needs_block_binary
+@pytest.mark.parametrize("scene,w,h,spp,per_launch,max_blocks,depth,shading", [
+    ("default", 75, 41, 7, 3, 4, 10, 0),          # every sample ends where it is made: one round per launch
+    ("materials", 70, 44, 6, 6, 5, 16, 0),        # samples that bounce on: a pixel's stream waits for its queued sample
+    ("materials", 33, 20, 5, 2, 1, 16, 0),        # one block owns every chunk; launches of 2, 2, 1
+    ("mirror", 48, 30, 4, 4, 2, 12, 1),           # extended shading: nearly every sample is queued -> a round per sample
+    ("soup", 60, 37, 5, 5, 3, 8, 0),
+])
+def test_wavefront_pass_sequential_streams_in_rounds(pt, oracle, tmp_path, scene, w, h, spp, per_launch, max_blocks, depth, shading):
+    """SEQUENTIAL streams (the reference's own: sample s+1 of a pixel starts where sample s stopped), several samples
+    per launch: bounces_block<true> makes a pixel's samples in a row while they end at once and runs a round of the
+    bounce loop for each that does not.  Image, final stream words and ray count against the oracle."""
+    cam = None
+    if scene == "default":
+        V, T, M = scenes.default_scene()
+    elif scene == "materials":
+        V, T, M = scenes.all_materials_scene()
+    elif scene == "mirror":
+        V, T, M = scenes.mirror_scene()
+    else:
+        V, T, M = scenes.triangle_soup(40, 5)
+        cam = oracle.make_camera(position=(0.05, -0.03, -0.1, 1.0), rotation=(0.03, 0.06, -0.02, 0.995), fov=70.0)
+    p = oracle.params(w, h, cam=cam, depth=depth, spp=spp, shading=shading)
+    ref, ref_rng, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M))
+    img, rng, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, cam=cam, shading=shading, wavefront=(per_launch, max_blocks))
+    assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
+
+
+@needs_block_binary
 def test_wavefront_pass_paths_that_bounce_on(pt, oracle, tmp_path):
     """all materials, depth 16: paths survive several bounces, so the block-private queues, their ping-pong and the
     producer-side resolution of terminal hits are all in play"""

@@ -19,12 +19,12 @@ import scenes                          # noqa: E402
 from oracle import pt_oracle_py as po  # noqa: E402
 
 
-def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pass=16, shading=0):
+def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pass=16, shading=0, sequential=False):
     V, T, M = scene
     # strided RNG so that the wavefront engine batches samples; the stride covers the worst case of the shading in use
     # (reference: 2 + 33 draws per bounce; extended: 2 + 2 per bounce).  The fused engine keeps the reference's own
     # sequential streams under reference shading.  Each run is checked against the oracle in its own mode.
-    strided = bool(shading) or engine == "wavefront"
+    strided = (bool(shading) or engine == "wavefront") and not sequential
     stride = 2 + (2 if shading else 33) * depth
     with pt.PathTracer(w, h) as tr:
         tr.set_scene(*pt.make_scene(V, T, M))
@@ -44,7 +44,7 @@ def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pa
         ref, _, _, _ = po.render(po.params(w, h, depth=depth, spp=spp, shading=shading, stride=stride,
                                            rng_mode=po.RNG_STRIDED if strided else po.RNG_SEQUENTIAL), scene=po.make_scene(V, T, M), pixel_ids=ids)
         ok = bool(np.array_equal(img[ids].view(np.uint32), ref.view(np.uint32)))
-    print(json.dumps({"config": name, "engine": engine, "triangles": len(T), "size": f"{w}x{h}", "spp": spp, "depth": depth, "rng": f"strided/{stride}" if strided else "sequential",
+    print(json.dumps({"config": name, "engine": engine, "samples_per_pass": samples_per_pass, "triangles": len(T), "size": f"{w}x{h}", "spp": spp, "depth": depth, "rng": f"strided/{stride}" if strided else "sequential",
                       "rays": int(st.rays), "rays_per_pixel_sample": round(st.rays / (w * h * spp), 3),
                       "device_ms": round(st.total_render_ms, 3), "wall_ms": round(dt * 1e3, 3),
                       "Mrays_per_s": round(st.rays / (st.total_render_ms * 1e-3) / 1e6, 1),
@@ -60,6 +60,17 @@ def main():
     if "c5" in which:
         for eng in ("fused", "wavefront"):
             run("C5 all materials depth 16", scenes.all_materials_scene(), 1920, 1080, args.spp, 16, eng)
+    if "seq" in which:
+        # the wavefront engine on the reference's own sequential streams: samples_per_pass = samples taken per launch
+        for per in (1, 16, 64):
+            run("default scene, sequential streams", scenes.default_scene(), 1920, 1080, args.spp, 10, "wavefront", samples_per_pass=per, sequential=True)
+        for per in (1, 64):
+            run("C5 all materials depth 16, sequential streams", scenes.all_materials_scene(), 1920, 1080, args.spp, 16, "wavefront", samples_per_pass=per, sequential=True)
+        run("C5 all materials depth 16, sequential streams", scenes.all_materials_scene(), 1920, 1080, args.spp, 16, "fused", sequential=True)
+    if "seq64" in which:
+        run("default scene, sequential streams", scenes.default_scene(), 1920, 1080, args.spp, 10, "wavefront", samples_per_pass=64, sequential=True)
+        run("C5 all materials depth 16, sequential streams", scenes.all_materials_scene(), 1920, 1080, args.spp, 16, "wavefront", samples_per_pass=64, sequential=True)
+        run("C5 mirror, extended shading, sequential", scenes.mirror_scene(), 1920, 1080, args.spp, 12, "wavefront", samples_per_pass=64, sequential=True, shading=1)
     if "c3" in which:
         # BASELINE configs[2], one rank's share: 3840x2160, samples [3*128, 4*128) of the 1024-sample frame (rank 3 of 8),
         # strided RNG stride 35 = the reference's own stream on this scene
