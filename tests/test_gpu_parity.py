@@ -230,6 +230,24 @@ def test_all_materials_depth16(pt, oracle, name, engine):
     assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
 
 
+@pytest.mark.parametrize("scene,shading,depth,per_launch", [("materials", 0, 16, 24), ("materials", 0, 16, 7), ("mirror", 1, 12, 24)])
+def test_wavefront_sequential_streams_in_rounds(pt, oracle, scene, shading, depth, per_launch):
+    """The wavefront engine on the reference's own streams with many samples per launch (bounces_block<true>: a pixel's
+    samples in a row while they end where they are made, a round of the bounce loop for each that is queued).  24 samples in
+    launches of 24 and of 7, 7, 7, 3; every pixel, the final stream words and the per-bounce ray counts against the oracle."""
+    V, T, M = scenes.all_materials_scene() if scene == "materials" else scenes.mirror_scene()
+    w, h, spp = 320, 180, 24
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, shading=shading), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=0, depth=depth, shading=shading, samples_per_pass=per_launch)
+        tr.render(spp)
+        img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+    assert_bit_equal(img, ref, f"{scene} in launches of {per_launch}")
+    assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
+    assert list(st.rays_per_bounce)[:depth] == [int(x) for x in st_ref.rays_per_bounce[:depth]]
+
+
 @pytest.fixture
 def brute_force_only(pt):
     """Scenes packed inside this fixture carry no BVH (reference-style loop over all triangles)."""
