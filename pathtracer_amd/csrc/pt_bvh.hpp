@@ -35,7 +35,7 @@ constexpr uint32_t kLeafSize = 4;                  // == ptd::kBvhLeafSize (pt_d
 constexpr float kEps32 = 5.9604645e-8f;            // 2^-24
 constexpr float kKappaScale = 16.0f * kEps32 / 0.000001f;
 
-// 64 bytes: the two children's boxes live in the parent.
+// What the builder works with: the two children's boxes live in the parent.
 struct Node {
 	float lo0[3], hi0[3];
 	float lo1[3], hi1[3];
@@ -43,6 +43,18 @@ struct Node {
 	float kappa0, kappa1;       // max kappa of the child's subtree
 };
 static_assert(sizeof(Node) == 64, "BVH node is 4 float4");
+
+// 32 bytes, what the traversal reads: the same node with its boxes on a 16-bit grid over the scene's bounding cube
+// (ptd::bvh_grid), lower corners rounded down, upper corners up, so a quantised box contains the exact one.  The node
+// walk is bound by the number of cache lines a wave's 64 lanes touch per step (every lane is at a different node):
+// two 16-byte loads per lane and step instead of four.  The per-child kappa is gone from the node: every box is
+// inflated for the scene's largest kappa, which is what the deepest boxes -- most of the tests -- needed anyway.
+struct QNode {
+	uint16_t lo0[3], hi0[3];
+	uint16_t lo1[3], hi1[3];
+	int32_t child0, child1;     // as Node
+};
+static_assert(sizeof(QNode) == 32, "quantised BVH node is 2 x 16 bytes");
 
 // 64 bytes: what the leaf test needs, in BVH order.  {v0.xyz, e0.x} {e0.yz, e1.xy} {e1.z, orig index bits, 0, 0} {pad}
 struct LeafTri { float f[16]; };
@@ -57,6 +69,36 @@ struct Built {
 };
 
 struct Prim { float lo[3], hi[3], c[3]; float kappa; uint32_t idx; };
+
+// x on the grid {glo + q * cell}: the largest q with glo + q*cell <= x (down) / the smallest with glo + q*cell >= x (up),
+// in double against the float grid the device uses, clamped to 16 bits (a clamped corner only happens for the far-away
+// box of a single-leaf root, which must not be entered anyway, or when x is outside the cube, which bvh_grid excludes)
+inline uint16_t grid_down(float x, float glo, float cell) {
+	double q = std::floor(((double)x - (double)glo) / (double)cell);
+	q = q >= 0.0 ? std::min(q, 65535.0) : 0.0;                 // (NaN -> 0)
+	while (q > 0.0 && (double)glo + q * (double)cell > (double)x) q -= 1.0;
+	return (uint16_t)q;
+}
+inline uint16_t grid_up(float x, float glo, float cell) {
+	double q = std::ceil(((double)x - (double)glo) / (double)cell);
+	q = q <= 65535.0 ? std::max(q, 0.0) : 65535.0;             // (NaN -> 65535)
+	while (q < 65535.0 && (double)glo + q * (double)cell < (double)x) q += 1.0;
+	return (uint16_t)q;
+}
+
+inline std::vector<QNode> quantize(const std::vector<Node>& nodes, const float glo[3], float cell) {
+	std::vector<QNode> out(nodes.size());
+	for (size_t i = 0; i < nodes.size(); i++) {
+		const Node& n = nodes[i];
+		QNode& q = out[i];
+		for (int k = 0; k < 3; k++) {
+			q.lo0[k] = grid_down(n.lo0[k], glo[k], cell); q.hi0[k] = grid_up(n.hi0[k], glo[k], cell);
+			q.lo1[k] = grid_down(n.lo1[k], glo[k], cell); q.hi1[k] = grid_up(n.hi1[k], glo[k], cell);
+		}
+		q.child0 = n.child0; q.child1 = n.child1;
+	}
+	return out;
+}
 
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
@@ -131,7 +173,7 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris) {
 		Node n{};
 		bounds_of(prims, 0, n_tris, n.lo0, n.hi0, n.kappa0);
 		n.child0 = root;
-		for (int k = 0; k < 3; k++) { n.lo1[k] = 1e30f; n.hi1[k] = 1e30f; }   // far-away point box: (almost) never entered; entering it re-tests one triangle, which is harmless
+		for (int k = 0; k < 3; k++) { n.lo1[k] = 1e30f; n.hi1[k] = -1e30f; }  // inside-out box (65535..0 on the grid): (almost) never entered; entering it re-tests one triangle, which is harmless
 		n.child1 = encode_leaf(0, 1);
 		n.kappa1 = 0.0f;
 		out.nodes.push_back(n);

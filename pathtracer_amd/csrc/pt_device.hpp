@@ -184,6 +184,14 @@ __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_ma
 }
 constexpr uint32_t kSceneMagic = 0x50544853u;  // "PTHS"
 
+// The 16-bit grid the BVH's boxes are stored on (pt_bvh.hpp QNode): a cube around the scene's bounding sphere,
+// x = lo + q * cell, q = 0..65535.  Host (scene_pack) and device evaluate this same function.
+__host__ __device__ inline void bvh_grid(const float center[3], float radius, float lo[3], float& cell) {
+	float half = 1.0001f * radius + 1e-6f;          // never zero, and a hair outside the sphere
+	for (int k = 0; k < 3; k++) lo[k] = center[k] - half;
+	cell = (2.0f * half) / 65534.0f;
+}
+
 // Moeller-Trumbore with culling, Functions.cuh:56-89.  Returns true and t unless the reference
 // returns NO_INTERSECTION.  e0/e1 are the precomputed v1-v0 / v2-v0 (same fp32 subtraction).
 // det_bounded (wave-uniform, SceneHeader::flags): every |e0|*|e1| of the scene is below 2^100, so for |d| < 2^20
@@ -272,7 +280,9 @@ __device__ __forceinline__ void intersect_range_primary(const float4* __restrict
 
 // ---- BVH traversal (pt_bvh.hpp): same answer as intersect_range over all triangles ----
 struct BvhView {
-	const float4* nodes;     // 4 float4 per node
+	const uint4* nodes;      // 2 x 16 bytes per node (pt_bvh.hpp QNode)
+	Vec3 glo;                // the box grid (bvh_grid): x = glo + q * cell
+	float cell, inv_cell;
 	const float4* leaves;    // 4 float4 per triangle, BVH order
 	float s_bound;           // bound on |ray origin - vertex| + edge length for any ray of this launch
 	float slack;             // absolute slack of the box arithmetic
@@ -286,7 +296,11 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	const SceneHeader* hdr = reinterpret_cast<const SceneHeader*>(scene);
 	uint32_t off = bvh_offset_of(n_tris, n_mats);
 	BvhView v;
-	v.nodes = reinterpret_cast<const float4*>(scene + off);
+	v.nodes = reinterpret_cast<const uint4*>(scene + off);
+	float glo[3];
+	bvh_grid(hdr->center, hdr->radius, glo, v.cell);
+	v.glo = Vec3{ glo[0], glo[1], glo[2] };
+	v.inv_cell = 1.0f / v.cell;
 	v.leaves = reinterpret_cast<const float4*>(scene + off + (size_t)n_tris * 64u);
 	float dx = origin.x - hdr->center[0], dy = origin.y - hdr->center[1], dz = origin.z - hdr->center[2];
 	// a ray starts at the camera or (within an epsilon) on a triangle, a vertex lies in the bounding sphere:
@@ -302,16 +316,17 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	return v;
 }
 
-// slab test of one child box inflated by `infl`; [tlo, thi] is the (widened) ray interval
-__device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, float hy, float hz, float infl,
-                                        Vec3 o, Vec3 inv, float tlo, float thi, float& tnear) {
-	float ax = (lx - infl - o.x) * inv.x, bx = (hx + infl - o.x) * inv.x;
-	float ay = (ly - infl - o.y) * inv.y, by = (hy + infl - o.y) * inv.y;
-	float az = (lz - infl - o.z) * inv.z, bz = (hz + infl - o.z) * inv.z;
+// Slab test of one child box in grid units.  ol / oh = the ray origin on the grid plus / minus the inflation, so
+// (l - ol) = (l - infl) - o and (h - oh) = (h + infl) - o; inv = cell / direction; [tlo, thi] is the (widened) ray interval.
+__device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, float hy, float hz,
+                                        Vec3 ol, Vec3 oh, Vec3 inv, float tlo, float thi, float& tnear) {
+	float ax = (lx - ol.x) * inv.x, bx = (hx - oh.x) * inv.x;
+	float ay = (ly - ol.y) * inv.y, by = (hy - oh.y) * inv.y;
+	float az = (lz - ol.z) * inv.z, bz = (hz - oh.z) * inv.z;
 	float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tlo));
 	float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), thi));
 	tnear = t0;
-	// widen by a relative hair for the products' own rounding (the absolute part is in infl)
+	// widen by a relative hair for the products' own rounding (the absolute part is in the inflation)
 	return t0 <= t1 + 1e-5f * fabsf(t1);
 }
 
@@ -355,24 +370,32 @@ constexpr int kBvhQuorum = PT_BVH_QUORUM;
 #endif
 
 struct BvhRay {              // per-ray constants of the box tests
-	Vec3 inv;                // 1 / direction
-	float s_ray, dt, tlo;
+	Vec3 inv;                // cell / direction: grid distance -> ray parameter
+	Vec3 ol, oh;             // origin on the grid + / - the inflation of every box (grid units)
+	float dt, tlo;
 };
 
-__device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 d, float best_t) {
+__device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 d, float best_t) {
 	// a zero component would make 0 * inf = NaN in the slabs; a direction error of 1e-20 is far inside the inflation
 	Vec3 dd{ fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x, fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y,
 	         fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z };
 	BvhRay r;
-	r.inv = Vec3{ 1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z };
+	r.inv = Vec3{ bv.cell / dd.x, bv.cell / dd.y, bv.cell / dd.z };
 	float dlen = __builtin_sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
 	// S for THIS ray: an accepted hit has computed t < best_t, so its vertex is no farther from the origin
 	// than best_t*|d| + edge (+ the error delta itself, bounded with the launch-wide S); never more than s_bound
 	float delta_max = bv.kappa_root * bv.s_bound + bv.slack;
-	r.s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
-	float delta_root = bv.kappa_root * r.s_ray + bv.slack;   // how far outside its triangle an accepted hit can be
+	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
+	float delta_root = bv.kappa_root * s_ray + bv.slack;     // how far outside its triangle an accepted hit can be
 	r.dt = 1.01f * delta_root / dlen;                        // ... in ray-parameter units
 	r.tlo = -r.dt;
+	// The origin in grid units.  Its own rounding (a subtraction, a product with the rounded 1/cell: under 4 ulp of a
+	// value that can reach 65535 + the camera's distance) and that of the slab's (q - o) go into the inflation, four
+	// times over: 1e-6 of the magnitudes involved -- hundredths of a cell, against boxes tens of cells wide.
+	Vec3 og{ (o.x - bv.glo.x) * bv.inv_cell, (o.y - bv.glo.y) * bv.inv_cell, (o.z - bv.glo.z) * bv.inv_cell };
+	float infl = 1.00001f * (delta_root * bv.inv_cell) + 1e-6f * (65536.0f + fabsf(og.x) + fabsf(og.y) + fabsf(og.z));
+	r.ol = Vec3{ og.x + infl, og.y + infl, og.z + infl };
+	r.oh = Vec3{ og.x - infl, og.y - infl, og.z - infl };
 	return r;
 }
 
@@ -402,13 +425,16 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 			if (leafy > 0 && (__popcll(walking) < kBvhQuorum || (PT_BVH_RATIO > 0 && __popcll(walking) * PT_BVH_RATIO < leafy * 4))) break;
 		}
 		if ((uint32_t)cur < (uint32_t)kBvhDone) {
-			const float4* n = bv.nodes + (size_t)cur * 4;
-			float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-			int32_t c0 = (int32_t)__float_as_uint(n3.x), c1 = (int32_t)__float_as_uint(n3.y);
+			const uint4* n = bv.nodes + (size_t)cur * 2;
+			uint4 w0 = n[0], w1 = n[1];
+			int32_t c0 = (int32_t)w1.z, c1 = (int32_t)w1.w;
 			float thi = best_t + r.dt + 1e-6f * best_t;
 			float tn0, tn1;
-			bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n3.z * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn0);
-			bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.w * r.s_ray + bv.slack, o, r.inv, r.tlo, thi, tn1);
+			// QNode: 12 grid coordinates, two to a word (exact as floats)
+			bool h0 = box_hit((float)(w0.x & 0xFFFFu), (float)(w0.x >> 16), (float)(w0.y & 0xFFFFu),
+			                  (float)(w0.y >> 16), (float)(w0.z & 0xFFFFu), (float)(w0.z >> 16), r.ol, r.oh, r.inv, r.tlo, thi, tn0);
+			bool h1 = box_hit((float)(w0.w & 0xFFFFu), (float)(w0.w >> 16), (float)(w1.x & 0xFFFFu),
+			                  (float)(w1.x >> 16), (float)(w1.y & 0xFFFFu), (float)(w1.y >> 16), r.ol, r.oh, r.inv, r.tlo, thi, tn1);
 			if (h0 && h1) {
 				bool first0 = tn0 <= tn1;
 				if (sp < bv.stack_depth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }     // never false: see bvh_stack_depth
@@ -430,7 +456,7 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 
 __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
                                               uint32_t* stack) {
-	BvhRay r = bvh_ray_setup(bv, d, best_t);
+	BvhRay r = bvh_ray_setup(bv, o, d, best_t);
 	int32_t cur = 0;
 	int sp = 0;
 	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack);
@@ -484,7 +510,7 @@ __device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origi
 					d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
 					best = FIRST ? FLT_MAX : b.z;
 					tri = kNoHit;
-					r = bvh_ray_setup(bv, d, best);
+					r = bvh_ray_setup(bv, o, d, best);
 					cur = 0; sp = 0; has_ray = true;
 				}
 			}

@@ -732,7 +732,10 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles);
 			if (bvh.nodes.size() > n_triangles) return fail(PT_ERR_LIMIT, "scene_pack: BVH larger than its reservation");
 			hdr.n_nodes = (uint32_t)bvh.nodes.size();
-			std::memcpy(base + hdr.bvh_offset, bvh.nodes.data(), bvh.nodes.size() * sizeof(ptbvh::Node));
+			float glo[3], cell;
+			bvh_grid(bvh.center, bvh.radius, glo, cell);
+			std::vector<ptbvh::QNode> qnodes = ptbvh::quantize(bvh.nodes, glo, cell);
+			std::memcpy(base + hdr.bvh_offset, qnodes.data(), qnodes.size() * sizeof(ptbvh::QNode));
 			std::memcpy(base + hdr.leaf_offset, bvh.tris.data(), bvh.tris.size() * sizeof(ptbvh::LeafTri));
 			for (int k = 0; k < 3; k++) hdr.center[k] = bvh.center[k];
 			hdr.radius = bvh.radius;

@@ -22,6 +22,7 @@
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
 struct Dim3Shim { unsigned x = 0, y = 0, z = 0; };
 static thread_local Dim3Shim threadIdx;
 static Dim3Shim blockIdx;
