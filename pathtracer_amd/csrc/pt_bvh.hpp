@@ -31,7 +31,11 @@
 
 namespace ptbvh {
 
-constexpr uint32_t kLeafSize = 4;                  // == ptd::kBvhLeafSize (pt_device.hpp: the traversal stack is sized from it)
+#ifndef PT_BVH_LEAF
+#define PT_BVH_LEAF 4                              // triangles per leaf, at most 8 (the leaf code keeps count - 1 in 3 bits)
+#endif
+constexpr uint32_t kLeafSize = PT_BVH_LEAF;        // == ptd::kBvhLeafSize (pt_device.hpp: the traversal stack is sized from it)
+static_assert(kLeafSize >= 1 && kLeafSize <= 8, "leaf code holds count - 1 in 3 bits");
 constexpr float kEps32 = 5.9604645e-8f;            // 2^-24
 constexpr float kKappaScale = 16.0f * kEps32 / 0.000001f;
 

@@ -172,7 +172,10 @@ constexpr uint32_t kBvhMinTris = 512;    // measured crossover on MI355X: brute 
 // Per-lane stack of deferred children, in LDS, [level][256 lanes].  The builder (pt_bvh.hpp) splits at the median down to
 // kBvhLeafSize triangles, so the tree is balanced and its inner depth -- the most the stack can ever hold, one deferred
 // sibling per level -- is known from the triangle count alone; 24 KiB for a fixed depth of 24 would cap a CU at 6 blocks.
-constexpr uint32_t kBvhLeafSize = 4;
+#ifndef PT_BVH_LEAF
+#define PT_BVH_LEAF 4
+#endif
+constexpr uint32_t kBvhLeafSize = PT_BVH_LEAF;     // == ptbvh::kLeafSize
 __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 	uint32_t d = 0;
 	while (n_tris > kBvhLeafSize) { n_tris = (n_tris + 1u) / 2u; d++; }    // the larger half decides
