@@ -44,24 +44,34 @@ BYTES_PER_RAY = (276.0 + 44.0 * P_LIGHT) / 2.0
 
 
 def cpu_baseline(spp):
-    """The oracle (kind 'port': our C restatement of the reference path) on the host cores."""
+    """The oracle (kind 'port': our C restatement of the reference path) on the host cores: `spp` samples over all of
+    them, and ('also report 1-thread') a twentieth of that on one thread."""
     from oracle import pt_oracle_py as po
+    import ctypes as C
     po.lib()
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
-    p = po.params(WIDTH, HEIGHT, depth=DEPTH, spp=spp, threads=cores)
     n = WIDTH * HEIGHT
-    rng = po.seed_states(1337, n)                       # RNG seeding excluded, as on the GPU side
-    mean = np.ones((n, 4), dtype=np.float32)
-    import ctypes as C
     v, t, m = po.default_scene()
-    st = po.Stats()
-    t0 = time.perf_counter()
-    rc = po.lib().pto_render(C.byref(p), C.cast(v, C.c_void_p), 8, C.cast(t, C.c_void_p), 4, C.cast(m, C.c_void_p), 2,
-                             None, 0, n, rng.ctypes.data, mean.ctypes.data, None, C.byref(st))
-    dt = time.perf_counter() - t0
-    assert rc == 0
-    return {"value": round(st.rays / dt / 1e6, 2), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"default scene {WIDTH}x{HEIGHT}, {spp} spp, depth {DEPTH}: {st.rays} rays in {dt:.2f} s wall"}
+
+    def timed(threads, samples):
+        p = po.params(WIDTH, HEIGHT, depth=DEPTH, spp=samples, threads=threads)
+        rng = po.seed_states(1337, n)                   # RNG seeding excluded, as on the GPU side
+        mean = np.ones((n, 4), dtype=np.float32)
+        st = po.Stats()
+        t0 = time.perf_counter()
+        rc = po.lib().pto_render(C.byref(p), C.cast(v, C.c_void_p), 8, C.cast(t, C.c_void_p), 4, C.cast(m, C.c_void_p), 2,
+                                 None, 0, n, rng.ctypes.data, mean.ctypes.data, None, C.byref(st))
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        return st.rays, dt
+
+    rays, dt = timed(cores, spp)
+    one_spp = max(1, spp // 20)
+    rays1, dt1 = timed(1, one_spp)
+    return {"value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"default scene {WIDTH}x{HEIGHT}, {spp} spp, depth {DEPTH}: {rays} rays in {dt:.2f} s wall",
+            "one_thread": {"value": round(rays1 / dt1 / 1e6, 2), "unit": "Mrays/s",
+                           "sample": f"{one_spp} spp: {rays1} rays in {dt1:.2f} s"}}
 
 
 def parity_sample(tracer, w, h, spp_total, n_pixels=2048):
