@@ -115,17 +115,44 @@ inline void bounds_of(const std::vector<Prim>& p, uint32_t a, uint32_t b, float 
 	}
 }
 
-// Median split on the widest centroid axis; leaves of up to kLeafSize triangles.
+// Median split, leaves of up to kLeafSize triangles: the tree stays balanced (the traversal stack is sized from that, see
+// ptd::bvh_stack_depth), and of the three axes the split goes along the one whose two halves have the smallest total
+// surface area (the surface-area heuristic's cost with the counts fixed at n/2 each) -- PT_BVH_AXIS_BY_AREA 0: the widest
+// centroid axis.
+#ifndef PT_BVH_AXIS_BY_AREA
+#define PT_BVH_AXIS_BY_AREA 1
+#endif
+inline float half_area(const float lo[3], const float hi[3]) {
+	float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+	return dx * dy + dy * dz + dz * dx;
+}
+
 inline int32_t build_range(std::vector<Prim>& p, uint32_t a, uint32_t b, Built& out) {
 	if (b - a <= kLeafSize) return encode_leaf(a, b - a);
-	float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
-	for (uint32_t i = a; i < b; i++)
-		for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], p[i].c[k]); chi[k] = std::max(chi[k], p[i].c[k]); }
-	int axis = 0;
-	for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
 	uint32_t mid = (a + b) / 2;
-	std::nth_element(p.begin() + a, p.begin() + mid, p.begin() + b,
-	                 [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
+	auto split = [&](int axis) {
+		std::nth_element(p.begin() + a, p.begin() + mid, p.begin() + b,
+		                 [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
+	};
+	int axis = 0;
+	if (PT_BVH_AXIS_BY_AREA) {
+		float best = INFINITY;
+		for (int k = 0; k < 3; k++) {
+			split(k);
+			float lo[3], hi[3], kappa;
+			bounds_of(p, a, mid, lo, hi, kappa);
+			float cost = half_area(lo, hi);
+			bounds_of(p, mid, b, lo, hi, kappa);
+			cost += half_area(lo, hi);
+			if (cost < best) { best = cost; axis = k; }       // (NaN costs never win; axis 0 then)
+		}
+	} else {
+		float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+		for (uint32_t i = a; i < b; i++)
+			for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], p[i].c[k]); chi[k] = std::max(chi[k], p[i].c[k]); }
+		for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+	}
+	split(axis);
 	uint32_t me = (uint32_t)out.nodes.size();
 	out.nodes.emplace_back();
 	Node n{};
