@@ -115,56 +115,150 @@ inline void bounds_of(const std::vector<Prim>& p, uint32_t a, uint32_t b, float 
 	}
 }
 
-// Median split, leaves of up to kLeafSize triangles: the tree stays balanced (the traversal stack is sized from that, see
-// ptd::bvh_stack_depth), and of the three axes the split goes along the one whose two halves have the smallest total
-// surface area (the surface-area heuristic's cost with the counts fixed at n/2 each) -- PT_BVH_AXIS_BY_AREA 0: the widest
-// centroid axis.
-#ifndef PT_BVH_AXIS_BY_AREA
-#define PT_BVH_AXIS_BY_AREA 1
+// Surface-area-heuristic split under a depth budget.  The traversal's stack (LDS, one deferred sibling per level) is
+// sized from the triangle count alone -- ptd::bvh_stack_depth(n) = the balanced depth + kDepthSlack -- so the builder may
+// unbalance the tree only as far as that allows: a subtree with `depth_left` levels to go holds at most
+// kLeafSize << depth_left triangles, and a split is admissible if both sides still fit one level down.  Within that
+// range the split minimises area(left) * n_left + area(right) * n_right over the three axes: a full sweep over the
+// sorted centroids for ranges up to kSweepMax triangles, 32 bins per axis above.  The slack of three levels leaves
+// the top of the tree unconstrained (the budget only bites where a subtree is already nearly full).
+// PT_BVH_SAH 0: the median along the axis whose halves have the smallest total area (the tree the first measurements
+// of DESIGN 4.4 were made with).
+#ifndef PT_BVH_SAH
+#define PT_BVH_SAH 1
 #endif
+constexpr uint32_t kSweepMax = 4096;
+constexpr int kBins = 32;
+
 inline float half_area(const float lo[3], const float hi[3]) {
 	float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
 	return dx * dy + dy * dz + dz * dx;
 }
 
-inline int32_t build_range(std::vector<Prim>& p, uint32_t a, uint32_t b, Built& out) {
-	if (b - a <= kLeafSize) return encode_leaf(a, b - a);
-	uint32_t mid = (a + b) / 2;
-	auto split = [&](int axis) {
-		std::nth_element(p.begin() + a, p.begin() + mid, p.begin() + b,
-		                 [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
-	};
-	int axis = 0;
-	if (PT_BVH_AXIS_BY_AREA) {
-		float best = INFINITY;
-		for (int k = 0; k < 3; k++) {
-			split(k);
-			float lo[3], hi[3], kappa;
-			bounds_of(p, a, mid, lo, hi, kappa);
-			float cost = half_area(lo, hi);
-			bounds_of(p, mid, b, lo, hi, kappa);
-			cost += half_area(lo, hi);
-			if (cost < best) { best = cost; axis = k; }       // (NaN costs never win; axis 0 then)
+struct Box {
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	void add(const Prim& q) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], q.lo[k]); hi[k] = std::max(hi[k], q.hi[k]); } }
+	void add(const Box& q) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], q.lo[k]); hi[k] = std::max(hi[k], q.hi[k]); } }
+	float area() const { return half_area(lo, hi); }
+};
+
+inline bool centroid_before(const Prim& x, const Prim& y, int axis) {
+	return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
+}
+
+// Reorders p[a, b) and returns the number of triangles that go left, within [min_left, max_left].
+inline uint32_t choose_split(std::vector<Prim>& p, uint32_t a, uint32_t b, uint32_t min_left, uint32_t max_left) {
+	const uint32_t n = b - a;
+	float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (uint32_t i = a; i < b; i++)
+		for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], p[i].c[k]); chi[k] = std::max(chi[k], p[i].c[k]); }
+	float best = INFINITY;
+	int best_axis = -1;
+	uint32_t best_left = 0;
+	int best_bin = -1;
+	if (PT_BVH_SAH && n <= kSweepMax) {
+		std::vector<float> right_area(n);
+		for (int axis = 0; axis < 3; axis++) {
+			std::sort(p.begin() + a, p.begin() + b, [axis](const Prim& x, const Prim& y) { return centroid_before(x, y, axis); });
+			Box r;
+			for (uint32_t i = n; i-- > 1;) { r.add(p[a + i]); right_area[i] = r.area(); }       // right_area[i]: triangles i..n-1
+			Box l;
+			for (uint32_t i = 1; i < n; i++) {
+				l.add(p[a + i - 1]);
+				if (i < min_left || i > max_left) continue;
+				float cost = l.area() * (float)i + right_area[i] * (float)(n - i);
+				if (cost < best) { best = cost; best_axis = axis; best_left = i; }
+			}
 		}
-	} else {
-		float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
-		for (uint32_t i = a; i < b; i++)
-			for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], p[i].c[k]); chi[k] = std::max(chi[k], p[i].c[k]); }
-		for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+	} else if (PT_BVH_SAH) {
+		for (int axis = 0; axis < 3; axis++) {
+			float width = chi[axis] - clo[axis];
+			if (!(width > 0.0f) || !std::isfinite(width)) continue;
+			Box bins[kBins];
+			uint32_t count[kBins] = {};
+			float scale = (float)kBins / width;
+			for (uint32_t i = a; i < b; i++) {
+				int k = std::min(kBins - 1, std::max(0, (int)((p[i].c[axis] - clo[axis]) * scale)));
+				bins[k].add(p[i]); count[k]++;
+			}
+			float right_area[kBins];
+			Box r;
+			for (int k = kBins - 1; k >= 1; k--) { r.add(bins[k]); right_area[k] = r.area(); }
+			Box l;
+			uint32_t nl = 0;
+			for (int k = 0; k + 1 < kBins; k++) {
+				l.add(bins[k]); nl += count[k];
+				if (nl < min_left || nl > max_left || nl == 0 || nl == n) continue;
+				float cost = l.area() * (float)nl + right_area[k + 1] * (float)(n - nl);
+				if (cost < best) { best = cost; best_axis = axis; best_left = nl; best_bin = k; }
+			}
+		}
 	}
-	split(axis);
+	if (best_axis >= 0 && best_bin >= 0) {
+		float lo = clo[best_axis], scale = (float)kBins / (chi[best_axis] - clo[best_axis]);
+		int axis = best_axis, bin = best_bin;
+		auto mid = std::partition(p.begin() + a, p.begin() + b, [=](const Prim& x) {
+			return std::min(kBins - 1, std::max(0, (int)((x.c[axis] - lo) * scale))) <= bin; });
+		return (uint32_t)(mid - (p.begin() + a));          // == best_left: the same expression binned them
+	}
+	if (best_axis >= 0) {
+		int axis = best_axis;
+		if (axis != 2) std::nth_element(p.begin() + a, p.begin() + a + best_left, p.begin() + b, [axis](const Prim& x, const Prim& y) { return centroid_before(x, y, axis); });
+		return best_left;                                   // (axis 2 was sorted last: already in order)
+	}
+	// no admissible plane (all centroids equal, NaNs, or PT_BVH_SAH 0): the median, along the axis whose halves are smallest
+	uint32_t left = std::min(std::max(n / 2, min_left), max_left);
+	int axis = 0;
+	best = INFINITY;
+	for (int k = 0; k < 3; k++) {
+		std::nth_element(p.begin() + a, p.begin() + a + left, p.begin() + b, [k](const Prim& x, const Prim& y) { return centroid_before(x, y, k); });
+		Box l, r;
+		for (uint32_t i = a; i < a + left; i++) l.add(p[i]);
+		for (uint32_t i = a + left; i < b; i++) r.add(p[i]);
+		float cost = l.area() + r.area();
+		if (cost < best) { best = cost; axis = k; }
+	}
+	std::nth_element(p.begin() + a, p.begin() + a + left, p.begin() + b, [axis](const Prim& x, const Prim& y) { return centroid_before(x, y, axis); });
+	return left;
+}
+
+inline int32_t build_range(std::vector<Prim>& p, uint32_t a, uint32_t b, uint32_t depth_left, Built& out) {
+	if (b - a <= kLeafSize) return encode_leaf(a, b - a);
+	// both sides must fit one level down: at most kLeafSize << (depth_left - 1) triangles each (depth_left >= 1 here, by
+	// the same invariant one level up; at the root it is ptd::bvh_stack_depth)
+	const uint64_t cap = (uint64_t)kLeafSize << std::min(depth_left - 1u, 40u);
+	const uint32_t n = b - a;
+	uint32_t min_left = (uint64_t)n > cap ? (uint32_t)(n - cap) : 1u;
+	uint32_t max_left = (uint32_t)std::min<uint64_t>(cap, n - 1u);
+	uint32_t mid = a + choose_split(p, a, b, std::max(min_left, 1u), max_left);
 	uint32_t me = (uint32_t)out.nodes.size();
 	out.nodes.emplace_back();
-	Node n{};
-	bounds_of(p, a, mid, n.lo0, n.hi0, n.kappa0);
-	bounds_of(p, mid, b, n.lo1, n.hi1, n.kappa1);
-	n.child0 = build_range(p, a, mid, out);
-	n.child1 = build_range(p, mid, b, out);
-	out.nodes[me] = n;
+	Node nd{};
+	bounds_of(p, a, mid, nd.lo0, nd.hi0, nd.kappa0);
+	bounds_of(p, mid, b, nd.lo1, nd.hi1, nd.kappa1);
+	nd.child0 = build_range(p, a, mid, depth_left - 1u, out);
+	nd.child1 = build_range(p, mid, b, depth_left - 1u, out);
+	out.nodes[me] = nd;
 	return (int32_t)me;
 }
 
-inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris) {
+// inner levels on the longest root-to-leaf path = the most deferred siblings a traversal can hold
+inline uint32_t inner_depth(const std::vector<Node>& nodes) {
+	if (nodes.empty()) return 0;
+	uint32_t deepest = 0;
+	std::vector<std::pair<int32_t, uint32_t>> todo{ { 0, 1u } };
+	while (!todo.empty()) {
+		auto [i, d] = todo.back();
+		todo.pop_back();
+		deepest = std::max(deepest, d);
+		if (nodes[(size_t)i].child0 >= 0) todo.push_back({ nodes[(size_t)i].child0, d + 1u });
+		if (nodes[(size_t)i].child1 >= 0) todo.push_back({ nodes[(size_t)i].child1, d + 1u });
+	}
+	return deepest;
+}
+
+// stack_depth: ptd::bvh_stack_depth(n_tris), what the traversal's stack holds
+inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, uint32_t stack_depth) {
 	Built out;
 	std::vector<Prim> prims(n_tris);
 	float slo[3] = { INFINITY, INFINITY, INFINITY }, shi[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -199,7 +293,7 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris) {
 	out.radius = std::sqrt(r2);
 	out.nodes.reserve(n_tris);
 	if (n_tris == 0) return out;
-	int32_t root = build_range(prims, 0, n_tris, out);
+	int32_t root = build_range(prims, 0, n_tris, stack_depth, out);
 	if (root < 0) {                                   // a single leaf: wrap it so the root is always node 0
 		Node n{};
 		bounds_of(prims, 0, n_tris, n.lo0, n.hi0, n.kappa0);

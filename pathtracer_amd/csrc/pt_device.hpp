@@ -169,17 +169,19 @@ static_assert(sizeof(SceneHeader) == 64, "SceneHeader is 64 bytes");
 
 // Scenes above this many triangles carry a BVH and are traversed with it (pt_bvh.hpp).
 constexpr uint32_t kBvhMinTris = 512;    // measured crossover on MI355X: brute force wins at 432 triangles, the BVH 2-3x at 972
-// Per-lane stack of deferred children, in LDS, [level][256 lanes].  The builder (pt_bvh.hpp) splits at the median down to
-// kBvhLeafSize triangles, so the tree is balanced and its inner depth -- the most the stack can ever hold, one deferred
-// sibling per level -- is known from the triangle count alone; 24 KiB for a fixed depth of 24 would cap a CU at 6 blocks.
+// Per-lane stack of deferred children, in LDS, [level][256 lanes]: one deferred sibling per inner level, so the tree's
+// depth is the most it can ever hold.  It is sized from the triangle count alone -- the depth of a balanced tree with
+// kBvhLeafSize triangles per leaf plus kBvhDepthSlack levels -- and the builder (pt_bvh.hpp) keeps its surface-area
+// splits inside that budget; 24 KiB for a fixed depth of 24 would cap a CU at 6 blocks.
 #ifndef PT_BVH_LEAF
 #define PT_BVH_LEAF 4
 #endif
 constexpr uint32_t kBvhLeafSize = PT_BVH_LEAF;     // == ptbvh::kLeafSize
+constexpr uint32_t kBvhDepthSlack = 3;     // levels the builder may spend on unbalanced (surface-area) splits, pt_bvh.hpp
 __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 	uint32_t d = 0;
 	while (n_tris > kBvhLeafSize) { n_tris = (n_tris + 1u) / 2u; d++; }    // the larger half decides
-	return d < 1u ? 1u : d;
+	return (d < 1u ? 1u : d) + kBvhDepthSlack;
 }
 
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {

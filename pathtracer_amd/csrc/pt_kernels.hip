@@ -729,8 +729,9 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 	{
 		// bounding sphere + (large scenes) the BVH: see pt_bvh.hpp for why the result stays the brute-force one
 		if (n_triangles > g_bvh_min_tris) {
-			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles);
+			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles, bvh_stack_depth(n_triangles));
 			if (bvh.nodes.size() > n_triangles) return fail(PT_ERR_LIMIT, "scene_pack: BVH larger than its reservation");
+			if (ptbvh::inner_depth(bvh.nodes) > bvh_stack_depth(n_triangles)) return fail(PT_ERR_LIMIT, "scene_pack: BVH deeper than the traversal stack");
 			hdr.n_nodes = (uint32_t)bvh.nodes.size();
 			float glo[3], cell;
 			bvh_grid(bvh.center, bvh.radius, glo, cell);

@@ -151,7 +151,9 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     seen = np.zeros(n_tris, dtype=int)
     kappa_root = float(hdr_f[13])
 
-    def visit(child, lo, hi):
+    deepest = [0]
+
+    def visit(child, lo, hi, depth=1):
         """checks containment: a quantised box holds its subtree's vertices EXACTLY (corners rounded outward, no tolerance)
         and lies inside its parent's"""
         if child < 0:
@@ -170,13 +172,20 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
         lo0, hi0, lo1, hi1 = glo + q[0:3] * cell, glo + q[3:6] * cell, glo + q[6:9] * cell, glo + q[9:12] * cell
         assert (lo0 >= lo).all() and (hi0 <= hi).all() and (lo1 >= lo).all() and (hi1 <= hi).all()
         # outward rounding costs at most one cell per face
-        visit(int(ni[6]), lo0, hi0)
-        visit(int(ni[7]), lo1, hi1)
+        deepest[0] = max(deepest[0], depth)
+        visit(int(ni[6]), lo0, hi0, depth + 1)
+        visit(int(ni[7]), lo1, hi1, depth + 1)
 
     import sys
     sys.setrecursionlimit(10000)
     visit(0, np.full(3, -np.inf), np.full(3, np.inf))
     assert (seen == 1).all()
+    # the traversal's stack is sized from the triangle count alone (bvh_stack_depth: balanced depth of 4-triangle leaves + 3
+    # levels of slack for surface-area splits); the builder must stay inside it
+    balanced, n = 0, n_tris
+    while n > 4:
+        n, balanced = (n + 1) // 2, balanced + 1
+    assert 0 < deepest[0] <= balanced + 3
     # the knob: brute force only
     assert lib.pt_hip_set_bvh_threshold(0xFFFFFFFF) == 0
     try:
