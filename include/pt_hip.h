@@ -114,7 +114,7 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* waits for 
 /* ---- scene: Vertex/Triangle/Material arrays (Structures.cuh:43-69, upload PathTracer.cu:48-77)
  * packed once on the host into the device blob the kernels stage in LDS: per triangle
  * {v0, e0=v1-v0, e1=v2-v0, n=cross(e0,e1), materialIdx}, per material {type, color}; above 512
- * triangles also a BVH (64-byte nodes + 64-byte leaf records).
+ * triangles also a BVH (32-byte nodes + 64-byte leaf records).
  * Validates vertex and material indices.  The blob is position independent: copy it to the
  * device with pt_hip_memcpy_h2d.  Entry points that take `scene_blob` also take the triangle and
  * material counts it was packed with. */

@@ -184,6 +184,7 @@ __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 	return (d < 1u ? 1u : d) + kBvhDepthSlack;
 }
 
+constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
@@ -306,7 +307,7 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	bvh_grid(hdr->center, hdr->radius, glo, v.cell);
 	v.glo = Vec3{ glo[0], glo[1], glo[2] };
 	v.inv_cell = 1.0f / v.cell;
-	v.leaves = reinterpret_cast<const float4*>(scene + off + (size_t)n_tris * 64u);
+	v.leaves = reinterpret_cast<const float4*>(scene + off + (size_t)n_tris * kBvhNodeBytes);
 	float dx = origin.x - hdr->center[0], dy = origin.y - hdr->center[1], dz = origin.z - hdr->center[2];
 	// a ray starts at the camera or (within an epsilon) on a triangle, a vertex lies in the bounding sphere:
 	// |origin - vertex| <= max(|camera - centre| + radius, 2 radius); plus the edge term of the error bound

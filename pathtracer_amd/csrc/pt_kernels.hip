@@ -695,8 +695,8 @@ int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_tria
 
 size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
 	size_t n = bvh_offset_of(n_triangles, n_materials);
-	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes and n_triangles leaf records, 64 B each
-	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * 128u;
+	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B
+	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u);
 	return n;
 }
 
@@ -725,7 +725,7 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 	hdr.magic = kSceneMagic;
 	hdr.blob_bytes = (uint32_t)pt_hip_scene_blob_bytes(n_triangles, n_materials);
 	hdr.bvh_offset = bvh_offset_of(n_triangles, n_materials);
-	hdr.leaf_offset = hdr.bvh_offset + n_triangles * 64u;
+	hdr.leaf_offset = hdr.bvh_offset + n_triangles * kBvhNodeBytes;
 	{
 		// bounding sphere + (large scenes) the BVH: see pt_bvh.hpp for why the result stays the brute-force one
 		if (n_triangles > g_bvh_min_tris) {

@@ -135,9 +135,10 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     hdr_u = raw[:64].view(np.uint32)
     hdr_f = raw[:64].view(np.float32)
     n_tris, n_nodes, bvh_off, leaf_off = int(hdr_u[0]), int(hdr_u[6]), int(hdr_u[7]), int(hdr_u[8])
-    assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 64 * n_tris
+    assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 32 * n_tris
     assert hdr_f[12] > 0 and hdr_f[13] > 0                       # radius, kappa_root
     # QNode, 32 bytes: 12 uint16 grid coordinates (lo0 hi0 lo1 hi1) + two child words; the grid is bvh_grid(center, radius)
+    assert n == bvh_off + (32 + 64) * n_tris                     # the blob: header, triangles, materials | nodes | leaf records
     nodes_q = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.uint16).reshape(n_nodes, 16)
     nodes_i = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.int32).reshape(n_nodes, 8)
     half = np.float32(1.0001) * hdr_f[12] + np.float32(1e-6)
