@@ -61,6 +61,10 @@ enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
  * reciprocal (5 VALU instructions for 11).  Set it ONLY after pt_hip_verify_fast_div has confirmed, for this width and
  * this height, that the short form returns the IEEE quotient for EVERY float32 numerator that can occur. */
 #define PT_FRAME_FAST_DIV 1u
+/* PT_FRAME_SCENE_BVH: the scene blob passed along with this frame carries a BVH (pt_hip_scene_has_bvh of the packed host
+ * blob) and is traversed with it.  Recorded per scene at pack time: the launchers dispatch on this bit, never on the
+ * process-wide threshold, so a blob packed under one threshold stays valid after pt_hip_set_bvh_threshold changes it. */
+#define PT_FRAME_SCENE_BVH 2u
 
 /* Which kernels execute a render call. */
 enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1 };
@@ -96,6 +100,7 @@ const char* pt_hip_last_error(void);
  *      cudaDeviceSynchronize calls, PathTracer.cu:25,71-77,88-96,167,217-233) ---- */
 int pt_hip_device_count(int* count);
 int pt_hip_set_device(int device);
+int pt_hip_get_device(int* device);          /* the calling thread's current device (cudaGetDevice) */
 int pt_hip_malloc(void** device_ptr, size_t bytes);
 int pt_hip_free(void* device_ptr);
 int pt_hip_memcpy_h2d(void* device_dst, const void* host_src, size_t bytes, void* stream);
@@ -118,11 +123,14 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* waits for 
  * Validates vertex and material indices.  The blob is position independent: copy it to the
  * device with pt_hip_memcpy_h2d.  Entry points that take `scene_blob` also take the triangle and
  * material counts it was packed with. */
-/* Process-wide tuning knob: scenes with more than `min_triangles` triangles get a BVH (default 512, the measured crossover;
- * 0xFFFFFFFF = always brute force like the reference).  Call before packing/uploading a scene; blobs
- * packed under another threshold must not be used afterwards.  Results do not depend on it. */
+/* Process-wide tuning knob for scenes packed FROM NOW ON: those with more than `min_triangles` triangles get a BVH
+ * (default 512, the measured crossover; 0xFFFFFFFF = always brute force like the reference).  Whether a packed blob
+ * carries one is recorded in the blob (pt_hip_scene_has_bvh) and handed to the kernels' launchers as
+ * PT_FRAME_SCENE_BVH in pt_frame.flags; blobs packed earlier stay valid.  Results do not depend on it. */
 int pt_hip_set_bvh_threshold(uint32_t min_triangles);
 size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials);
+/* 1 if the packed HOST blob carries a BVH, 0 if not, negative pt_status if it is not a scene blob. */
+int pt_hip_scene_has_bvh(const void* host_blob, size_t blob_bytes);
 int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
                       const pt_triangle* triangles, uint32_t n_triangles,
                       const pt_material* materials, uint32_t n_materials,

@@ -25,6 +25,7 @@ PT_ENGINE_WAVEFRONT, PT_ENGINE_FUSED = 0, 1
 PT_MAT_DIFFUSE, PT_MAT_REFLECTIVE, PT_MAT_EMISSIVE = 0, 1, 2
 PT_SHADING_REFERENCE, PT_SHADING_EXTENDED = 0, 1
 PT_FRAME_FAST_DIV = 1
+PT_FRAME_SCENE_BVH = 2
 PT_MAX_DEPTH = 32
 PT_STATS_WORDS = 4 + PT_MAX_DEPTH
 
@@ -120,6 +121,7 @@ SYMBOLS = {
     "pt_hip_last_error": (C.c_char_p, []),
     "pt_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "pt_hip_set_device": (C.c_int, [C.c_int]),
+    "pt_hip_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "pt_hip_malloc": (C.c_int, [C.POINTER(_VP), _SZ]),
     "pt_hip_free": (C.c_int, [_VP]),
     "pt_hip_memcpy_h2d": (C.c_int, [_VP, _VP, _SZ, _VP]),
@@ -136,6 +138,7 @@ SYMBOLS = {
     "pt_hip_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
     "pt_hip_set_bvh_threshold": (C.c_int, [_U32]),
     "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),
+    "pt_hip_scene_has_bvh": (C.c_int, [_VP, _SZ]),
     "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
     "pt_hip_verify_fast_div": (C.c_int, [_U32, C.POINTER(C.c_int), _VP]),
     "pt_hip_rng_seed": (C.c_int, [_FRAMEP, _VP, _VP]),

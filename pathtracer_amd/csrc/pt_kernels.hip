@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,15 +62,25 @@ int hip_fail(hipError_t e, const char* what) {
 }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
 
-int grid_for(size_t work_items) {
-	static int cus = 0;
-	if (cus == 0) {
-		int dev = 0; hipDeviceProp_t prop;
-		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-		if (cus <= 0) cus = 256;
+// CU count of the calling thread's current device, cached per device ordinal (instances on different GPUs of one
+// process each size their grids -- and their queue geometry -- for their own device)
+int device_cus() {
+	constexpr int kMaxDevices = 64;
+	static std::atomic<int> cus[kMaxDevices];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+	int n = cus[dev].load(std::memory_order_relaxed);
+	if (n == 0) {
+		hipDeviceProp_t prop;
+		n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+		cus[dev].store(n, std::memory_order_relaxed);
 	}
+	return n;
+}
+
+int grid_for(size_t work_items) {
 	size_t blocks = (work_items + kBlock - 1) / kBlock;
-	size_t cap = (size_t)cus * 8;                   // 8 blocks of 256 per CU = 32 waves per CU
+	size_t cap = (size_t)device_cus() * 8;          // 8 blocks of 256 per CU = 32 waves per CU
 	return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
 
@@ -132,7 +143,7 @@ struct JumpMat { uint32_t cols[32]; };
 __device__ __forceinline__ bool scene_det_bounded(const unsigned char* scene) {
 	return scene && (reinterpret_cast<const SceneHeader*>(scene)->flags & kSceneDetBounded) != 0;
 }
-struct SceneInfo { uint32_t n_tris, n_mats; };
+struct SceneInfo { uint32_t n_tris, n_mats; bool bvh; };        // bvh: PT_FRAME_SCENE_BVH of the frame the blob came with
 
 // ------------------------------------------------------------------------------- kernels
 
@@ -574,8 +585,14 @@ size_t carve(Workspace* w, unsigned char* base, uint32_t pixel_count, uint32_t s
 	return off;
 }
 
-uint32_t g_bvh_min_tris = kBvhMinTris;       // pt_hip_set_bvh_threshold
-bool scene_has_bvh(const SceneInfo& s) { return s.n_tris > g_bvh_min_tris; }
+uint32_t g_bvh_min_tris = kBvhMinTris;       // pt_hip_set_bvh_threshold: scenes packed from now on
+// recorded per scene at pack time (SceneHeader::n_nodes, pt_hip_scene_has_bvh) and passed with the frame
+bool scene_has_bvh(const SceneInfo& s) { return s.bvh; }
+SceneInfo scene_info(const pt_frame* f, uint32_t n_tris, uint32_t n_mats) { return SceneInfo{ n_tris, n_mats, (f->flags & PT_FRAME_SCENE_BVH) != 0 }; }
+// dynamic LDS of the one-launch pass (k_bounces): triangles, materials, camera-ray records; beside them 8.5 KiB of static
+// tables.  The pass is taken only when that fits the 160 KiB of a CU (1536 triangles with 256 materials would not).
+size_t bounces_lds_bytes(const SceneInfo& s) { return (size_t)s.n_tris * (sizeof(TriRec) + sizeof(PrimRec)) + (size_t)s.n_mats * sizeof(MatRec); }
+constexpr size_t kBouncesLdsBudget = 160u * 1024u - 9u * 1024u;
 
 void launch_extend(const FrameDev& f, uint32_t bounce, const void* scene_blob, const SceneInfo& si, const float4* qa, const float4* qb,
                    const uint32_t* counts, uint32_t capacity, uint2* hit, hipStream_t s) {
@@ -621,6 +638,11 @@ int pt_hip_device_count(int* count) {
 	return PT_OK;
 }
 int pt_hip_set_device(int device) { HIP_TRY(hipSetDevice(device)); return PT_OK; }
+int pt_hip_get_device(int* device) {
+	if (!device) return fail(PT_ERR_INVALID, "device is null");
+	HIP_TRY(hipGetDevice(device));
+	return PT_OK;
+}
 int pt_hip_malloc(void** device_ptr, size_t bytes) {
 	if (!device_ptr) return fail(PT_ERR_INVALID, "device_ptr is null");
 	*device_ptr = nullptr;
@@ -698,6 +720,14 @@ size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
 	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B
 	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u);
 	return n;
+}
+
+int pt_hip_scene_has_bvh(const void* host_blob, size_t blob_bytes) {
+	if (!host_blob || blob_bytes < sizeof(SceneHeader)) return fail(PT_ERR_INVALID, "scene_has_bvh: not a scene blob");
+	SceneHeader hdr;
+	std::memcpy(&hdr, host_blob, sizeof(hdr));
+	if (hdr.magic != kSceneMagic || hdr.blob_bytes > blob_bytes) return fail(PT_ERR_INVALID, "scene_has_bvh: not a scene blob");
+	return hdr.n_nodes != 0 ? 1 : 0;
 }
 
 int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
@@ -845,7 +875,7 @@ int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob
 	if (int rc = check_frame(frame)) return rc;
 	if (!scene_blob || !in.b || !count || !hit || (bounce > 0 && !in.a)) return fail(PT_ERR_INVALID, "extend: null pointer");
 	if (capacity == 0) return PT_OK;
-	launch_extend(to_dev(*frame), bounce, scene_blob, SceneInfo{ n_triangles, n_materials }, (const float4*)in.a, (const float4*)in.b,
+	launch_extend(to_dev(*frame), bounce, scene_blob, scene_info(frame, n_triangles, n_materials), (const float4*)in.a, (const float4*)in.b,
 	              count, capacity, (uint2*)hit, (hipStream_t)stream);
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
@@ -880,7 +910,7 @@ int pt_hip_shade(const pt_frame* frame, const void* scene_blob, uint32_t n_trian
 	if (bounce >= frame->depth) return fail(PT_ERR_INVALID, "shade: bounce must be < depth");
 	if (frame->rng_mode == PT_RNG_SEQUENTIAL && !rng) return fail(PT_ERR_INVALID, "shade: sequential RNG needs rng");
 	if (capacity == 0) return PT_OK;
-	SceneInfo si{ n_triangles, n_materials };
+	SceneInfo si = scene_info(frame, n_triangles, n_materials);
 	return launch_shade(to_dev(*frame), scene_blob, si, bounce, in, hit, count_in, capacity, out, hit_out, count_out, radiance, lit,
 	                    frame->rng_mode == PT_RNG_SEQUENTIAL ? rng : nullptr, (hipStream_t)stream);
 }
@@ -904,10 +934,13 @@ size_t pt_hip_wavefront_workspace_bytes(uint32_t pixel_count, uint32_t samples_p
 	return carve(&w, nullptr, pixel_count, samples_per_pass);
 }
 
-int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
-                            uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
-                            uint32_t samples_per_pass, uint32_t* rng, void* mean,
-                            void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream) {
+// Both wavefront entry points: the workspace is the caller's (pt_hip_render_wavefront) or the library's own static
+// array (pt_hip_render_wavefront_noalloc).  Nothing in here allocates device memory, and nothing in the workspace is
+// read before this call has written it (queues, flags, counters, masks), so a workspace may hold anything on entry.
+static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                                 uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                                 uint32_t samples_per_pass, uint32_t* rng, void* mean,
+                                 void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream) {
 	if (int rc = check_frame(frame)) return rc;
 	if (!scene_blob || !rng || !mean || !workspace) return fail(PT_ERR_INVALID, "render_wavefront: null pointer");
 	if (n_samples == 0 || frame->pixel_count == 0) return PT_OK;
@@ -923,11 +956,11 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	if (carve(&w, (unsigned char*)workspace, frame->pixel_count, samples_per_pass) > workspace_bytes) return fail(PT_ERR_NOMEM, "render_wavefront: workspace too small");
 	if (((uintptr_t)workspace & 255u) != 0) return fail(PT_ERR_INVALID, "render_wavefront: workspace must be 256-byte aligned");
 	hipStream_t s = (hipStream_t)stream;
-	SceneInfo si{ n_triangles, n_materials };
+	SceneInfo si = scene_info(frame, n_triangles, n_materials);
 	FrameDev f = to_dev(*frame);
 	const bool sequential = frame->rng_mode == PT_RNG_SEQUENTIAL;
 	// scene resident in LDS: the whole pass is one launch (k_bounces)
-	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si);
+	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si) && bounces_lds_bytes(si) <= kBouncesLdsBudget;
 	if (!fuse) per_launch = samples_per_pass;
 	per_launch = std::min(per_launch, 0x7FFFFFFFu);          // bounces_block<true> keeps a flag in the sample index's top bit
 	// queue blocks: fixed for every stage of every pass
@@ -951,7 +984,7 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 				host_jump_matrix(frame->stride, per.cols);
 			}
 			if (done == 0 && stats) HIP_TRY(hipMemsetAsync(w.ray_counts, 0, (size_t)(frame->depth + 1) * G * sizeof(uint32_t), s));
-			size_t lds_bytes = shade_lds_bytes(si) + (size_t)si.n_tris * sizeof(PrimRec);
+			size_t lds_bytes = bounces_lds_bytes(si);
 #define PT_BOUNCES(SEQ) hipLaunchKernelGGL(k_bounces<SEQ>, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, \
 			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1], \
 			                   w.ray_counts, slots, w.radiance, w.lit, SEQ ? rng : nullptr, \
@@ -980,6 +1013,14 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
 	return PT_OK;
 }
 
+int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                            uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                            uint32_t samples_per_pass, uint32_t* rng, void* mean,
+                            void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream) {
+	return render_wavefront_impl(frame, scene_blob, n_triangles, n_materials, frame_first, mean_first, n_samples, samples_per_pass,
+	                             rng, mean, workspace, workspace_bytes, stats, stream);
+}
+
 int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                         uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
                         uint32_t* rng, void* mean, uint64_t* stats, void* stream) {
@@ -987,7 +1028,7 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	if (!scene_blob || !rng || !mean) return fail(PT_ERR_INVALID, "render_fused: null pointer");
 	if (n_samples == 0 || frame->pixel_count == 0) return PT_OK;
 	hipStream_t s = (hipStream_t)stream;
-	SceneInfo si{ n_triangles, n_materials };
+	SceneInfo si = scene_info(frame, n_triangles, n_materials);
 	FrameDev f = to_dev(*frame);
 	JumpMat first{}, per{};
 	bool strided = frame->rng_mode == PT_RNG_STRIDED;
@@ -1017,7 +1058,8 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 
 int pt_hip_combine_shards(const void* shard_means, uint32_t shards, size_t n_pixels, void* out, void* stream) {
 	if (!shard_means || !out) return fail(PT_ERR_INVALID, "combine_shards: null pointer");
-	if (shards == 0 || shards > 64 || (shards & (shards - 1))) return fail(PT_ERR_INVALID, "combine_shards: shards must be a power of two <= 16");
+	if (shards == 0 || (shards & (shards - 1))) return fail(PT_ERR_INVALID, "combine_shards: shards must be a power of two");
+	if (shards > 16) return fail(PT_ERR_LIMIT, "combine_shards: at most 16 shards");
 	if (n_pixels == 0) return PT_OK;
 	dim3 grid(grid_for(n_pixels)), block(kBlock);
 	hipStream_t s = (hipStream_t)stream;
@@ -1029,7 +1071,7 @@ int pt_hip_combine_shards(const void* shard_means, uint32_t shards, size_t n_pix
 	case 4: hipLaunchKernelGGL(k_combine<4>, grid, block, 0, s, in, n_pixels, o); break;
 	case 8: hipLaunchKernelGGL(k_combine<8>, grid, block, 0, s, in, n_pixels, o); break;
 	case 16: hipLaunchKernelGGL(k_combine<16>, grid, block, 0, s, in, n_pixels, o); break;
-	default: return fail(PT_ERR_LIMIT, "combine_shards: at most 16 shards");
+	default: return fail(PT_ERR_LIMIT, "combine_shards: at most 16 shards");     // not reached: checked above
 	}
 	HIP_TRY(hipGetLastError());
 	return PT_OK;

@@ -39,6 +39,24 @@ int hip_layer_fail(int code, const char* where) {
 }
 #define PT_TRY(expr) do { int rc_ = (expr); if (rc_ != PT_OK) return hip_layer_fail(rc_, #expr); } while (0)
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the object and puts the previous one back
+// afterwards.  The reference binds its device once (cudaSetDevice, PathTracer.cu:25) because it owns the process; a
+// library that several instances -- one per GPU, each driven from any thread -- share must not rely on, nor change,
+// what the caller has current: every method that allocates, copies or launches opens one of these first.
+class DeviceScope {
+	int _previous = -1;
+	bool _switched = false;
+public:
+	explicit DeviceScope(int device) {
+		if (device < 0) return;
+		if (pt_hip_get_device(&_previous) != PT_OK) return;
+		if (_previous != device) _switched = pt_hip_set_device(device) == PT_OK;
+	}
+	~DeviceScope() { if (_switched) pt_hip_set_device(_previous); }
+	DeviceScope(const DeviceScope&) = delete;
+	DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 // The reference's literal scene, PathTracer.cu:48-69.
 void DefaultScene(std::vector<pt_vertex>& v, std::vector<pt_triangle>& t, std::vector<pt_material>& m) {
 	const float V[8][4] = {
@@ -73,6 +91,8 @@ class PathTracer final : public IPathTracer {
 	} _dev;
 	size_t _workspaceBytes = 0;
 	uint32_t _nTris = 0, _nMats = 0;
+	bool _sceneHasBvh = false;          // recorded when the scene is packed (pt_hip_scene_has_bvh), passed with every frame
+	int _device = -1;                   // resolved HIP ordinal of this instance, bound by every method (DeviceScope)
 	void* _stream = nullptr;
 	void* _evStart = nullptr;
 	void* _evStop = nullptr;
@@ -100,7 +120,11 @@ public:
 		int count = 0;
 		PT_TRY(pt_hip_device_count(&count));
 		if (count <= 0) return plugin_fail(PT_ERR_HIP, "no HIP device visible");
-		if (_opt.device >= 0) PT_TRY(pt_hip_set_device(_opt.device));
+		if (_opt.device >= count) return plugin_fail(PT_ERR_INVALID, "device ordinal beyond the visible HIP devices");
+		if (_opt.device >= 0) _device = _opt.device;
+		else PT_TRY(pt_hip_get_device(&_device));            // "whatever is current" is resolved once, here
+		_opt.device = _device;
+		DeviceScope bind(_device);
 		std::cout << "Found " << count << " HIP device(s); path tracer running headless" << std::endl;
 		PT_TRY(pt_hip_stream_create(&_stream));
 		PT_TRY(pt_hip_event_create(&_evStart));
@@ -109,12 +133,12 @@ public:
 		if (int rc = _AllocateDrawingMemory()) return rc;
 		std::vector<pt_vertex> v; std::vector<pt_triangle> t; std::vector<pt_material> m;
 		DefaultScene(v, t, m);
-		if (int rc = SetScene(v.data(), 8, t.data(), 4, m.data(), 2)) return rc;
-		return _InitializeRendering();
+		return SetScene(v.data(), 8, t.data(), 4, m.data(), 2);      // seeds the streams too (_InitializeRendering)
 	}
 
 	~PathTracer() {
 		std::cout << "Terminating HIP path tracer" << std::endl;
+		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		if (_stream) pt_hip_stream_synchronize(_stream);
 		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.scene);
@@ -129,6 +153,7 @@ public:
 	}
 
 	void BeginDrawing() override {
+		DeviceScope bind(_device);
 		_drawState = Drawing;
 		_inFlightSamples = 0;
 		if (_error) return;
@@ -140,6 +165,7 @@ public:
 
 	void FinalizeDrawing() override {
 		if (_drawState != Drawing) return;
+		DeviceScope bind(_device);
 		_drawState = Idle;
 		if (_error) return;
 		float ms = 0.0f;
@@ -154,6 +180,7 @@ public:
 
 	void Resize(const int pixelWidth, const int pixelHeight) override {
 		if (pixelWidth <= 0 || pixelHeight <= 0) { _error = plugin_fail(PT_ERR_INVALID, "Resize: width and height must be positive"); return; }
+		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		_width = pixelWidth;
 		_height = pixelHeight;
@@ -168,6 +195,7 @@ public:
 
 	int Render(uint32_t spp) {
 		if (_error) return _error;
+		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		_drawState = Drawing;
 		_inFlightSamples = 0;
@@ -193,6 +221,7 @@ public:
 		uint64_t cnt = in.pixel_count ? in.pixel_count : n - std::min<uint64_t>(in.pixel_first, n);
 		if ((uint64_t)in.pixel_first + cnt > n || cnt == 0) return plugin_fail(PT_ERR_INVALID, "pixel range exceeds the image");
 		if (in.device != _opt.device && in.device >= 0) return plugin_fail(PT_ERR_STATE, "device is chosen before Create (pt_set_default_device)");
+		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		bool realloc = in.pixel_first != _opt.pixel_first || in.pixel_count != _opt.pixel_count ||
 		               in.samples_per_pass != _opt.samples_per_pass || in.engine != _opt.engine || in.rng_mode != _opt.rng_mode;
@@ -204,23 +233,29 @@ public:
 		return _error = _InitializeRendering();
 	}
 
+	// Restarts accumulation right away, like SetOptions and Resize (PathTracer.cu:176-184): a flag would be overwritten by
+	// the next Update(same camera) (PathTracer.cu:99-101) and the new scene's samples folded into the old scene's mean.
 	int SetScene(const pt_vertex* v, uint32_t nv, const pt_triangle* t, uint32_t nt, const pt_material* m, uint32_t nm) {
+		if (_error) return _error;
+		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		size_t bytes = pt_hip_scene_blob_bytes(nt, nm);
 		std::vector<unsigned char> blob(bytes);
 		PT_TRY(pt_hip_scene_pack(v, nv, t, nt, m, nm, blob.data(), bytes));
+		int has_bvh = pt_hip_scene_has_bvh(blob.data(), bytes);
+		if (has_bvh < 0) return hip_layer_fail(has_bvh, "pt_hip_scene_has_bvh");
 		void* fresh = nullptr;
 		PT_TRY(pt_hip_malloc(&fresh, bytes));
 		if (int rc = pt_hip_memcpy_h2d(fresh, blob.data(), bytes, _stream)) { pt_hip_free(fresh); return hip_layer_fail(rc, "scene upload"); }
 		PT_TRY(pt_hip_stream_synchronize(_stream));
 		pt_hip_free(_dev.scene);
-		_dev.scene = fresh; _nTris = nt; _nMats = nm;
-		_shouldRestartRendering = true;
-		return PT_OK;
+		_dev.scene = fresh; _nTris = nt; _nMats = nm; _sceneHasBvh = has_bvh != 0;
+		return _error = _InitializeRendering();
 	}
 
 	int Readback(float* rgba, size_t n_floats) {
 		if (_error) return _error;
+		DeviceScope bind(_device);
 		if (!rgba) return plugin_fail(PT_ERR_INVALID, "readback: null pointer");
 		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "readback: n_floats must be 4 * pixel_count");
 		if (_drawState == Drawing) FinalizeDrawing();
@@ -229,6 +264,7 @@ public:
 	}
 	int ReadbackRng(uint32_t* states, size_t n) {
 		if (_error) return _error;
+		DeviceScope bind(_device);
 		if (!states) return plugin_fail(PT_ERR_INVALID, "readback_rng: null pointer");
 		if (n != _pixelCount) return plugin_fail(PT_ERR_INVALID, "readback_rng: n must be pixel_count");
 		if (_drawState == Drawing) FinalizeDrawing();
@@ -237,6 +273,7 @@ public:
 	}
 	int CopyMean(void* device_dst, size_t n_floats) {
 		if (_error) return _error;
+		DeviceScope bind(_device);
 		if (!device_dst) return plugin_fail(PT_ERR_INVALID, "copy_mean: null pointer");
 		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "copy_mean: n_floats must be 4 * pixel_count");
 		if (_drawState == Drawing) FinalizeDrawing();
@@ -246,6 +283,7 @@ public:
 	}
 	int CopyMeanAsync(void* device_dst, size_t n_floats) {
 		if (_error) return _error;
+		DeviceScope bind(_device);
 		if (!device_dst) return plugin_fail(PT_ERR_INVALID, "copy_mean_async: null pointer");
 		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "copy_mean_async: n_floats must be 4 * pixel_count");
 		PT_TRY(pt_hip_memcpy_d2d(device_dst, _dev.mean, n_floats * sizeof(float), _stream));
@@ -253,9 +291,11 @@ public:
 	}
 	void* Stream() const { return _stream; }
 	void* DeviceMean() { if (_drawState == Drawing) FinalizeDrawing(); return _dev.mean; }
+	int Device() const { return _device; }
 
 	int Stats(pt_stats* out) {
 		if (_error) return _error;
+		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		uint64_t words[PT_STATS_WORDS];
 		PT_TRY(pt_hip_memcpy_d2h(words, _dev.stats, sizeof(words), _stream));
@@ -280,7 +320,7 @@ private:
 		f.pixel_first = _pixelFirst; f.pixel_count = _pixelCount;
 		f.depth = _opt.depth; f.seed = _opt.seed; f.rng_mode = _opt.rng_mode; f.stride = _opt.stride;
 		f.shading = _opt.shading;
-		f.flags = _frameFlags;
+		f.flags = _frameFlags | (_sceneHasBvh ? PT_FRAME_SCENE_BVH : 0u);
 		f.origin = _camera.GetPosition();
 		f.top_left = _camera.GetTopLeft();
 		f.bottom_left = _camera.GetBottomLeft();

@@ -88,7 +88,9 @@ __device__ __forceinline__ void shade_lane(const ShadeCtx& c, bool extended, uin
 		r.cont = true;
 		if (EXTEND && !last_bounce) intersect_range(c.tris, 0, c.n_tris, c.det_bounded, r.o, r.d, r.t, r.next_tri);
 		if (RESOLVE) {
-			r.traced = !last_bounce;
+			// counted in the row of the NEXT bounce: for a bounce below the depth those are its rays; in the row `depth` (no
+			// rays are traced for it) they are the shades of the last bounce, which the statistics count like any other
+			r.traced = true;
 			r.cont = false;
 			if (!last_bounce && r.next_tri != kNoHit) {
 				uint32_t m2 = __float_as_uint(c.tris[4 * r.next_tri + 3].x);

@@ -46,15 +46,19 @@ def upload_scene(pt, lib, scene):
     rc = lib.pt_hip_scene_pack(C.cast(v, C.c_void_p), len(v), C.cast(t, C.c_void_p), len(t), C.cast(m, C.c_void_p), len(m),
                                C.cast(blob, C.c_void_p), n)
     assert rc == 0, lib.pt_hip_last_error()
-    return DeviceBuffer(lib, n).upload(np.frombuffer(blob, dtype=np.uint8))
+    buf = DeviceBuffer(lib, n).upload(np.frombuffer(blob, dtype=np.uint8))
+    has_bvh = lib.pt_hip_scene_has_bvh(C.cast(blob, C.c_void_p), n)
+    assert has_bvh in (0, 1), lib.pt_hip_last_error()
+    buf.frame_flags = pt.PT_FRAME_SCENE_BVH if has_bvh else 0      # OR into pt_frame.flags of every call that takes this blob
+    return buf
 
 
-def make_frame(pt, oracle, w, h, cam=None, pixel_first=0, pixel_count=None, depth=10, seed=1337, rng_mode=0, stride=35):
+def make_frame(pt, oracle, w, h, cam=None, pixel_first=0, pixel_count=None, depth=10, seed=1337, rng_mode=0, stride=35, flags=0):
     cam = cam or oracle.default_camera()
     c = oracle.camera_corners(cam, np.float32(w) / np.float32(h))
     f4 = lambda v: pt.Float4(v.x, v.y, v.z, v.w)
     return pt.Frame(width=w, height=h, pixel_first=pixel_first, pixel_count=w * h - pixel_first if pixel_count is None else pixel_count,
-                    depth=depth, seed=seed, rng_mode=rng_mode, stride=stride,
+                    depth=depth, seed=seed, rng_mode=rng_mode, stride=stride, flags=flags,
                     origin=f4(c[0]), top_left=f4(c[1]), bottom_left=f4(c[2]), bottom_right=f4(c[3]))
 
 

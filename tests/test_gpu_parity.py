@@ -481,3 +481,107 @@ def test_engines_agree_at_full_size_and_sampled_pixels_match_oracle(pt, oracle):
     img = imgs["fused"]
     assert np.isfinite(img).all()
     assert 0.3 < img[:, 0].mean() < 0.45 and abs(img[:, 1].mean() - 0.2 * img[:, 0].mean()) < 1e-4
+
+
+# ---------------------------------------------------------------- round-2 regressions
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_scene_change_restarts_even_if_update_follows(pt, oracle, name, engine):
+    """set_scene -> Update(same camera) -> render: Update overwrites the restart flag like the reference's does
+    (PathTracer.cu:99-101), so the scene change must restart on its own -- else the new scene's samples would be folded
+    into the old scene's mean with the old streams."""
+    w, h, spp = 96, 54, 3
+    V, T, M = scenes.all_materials_scene()
+    ref, ref_rng, _, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_options(engine=engine)
+        tr.render(2)                                  # two samples of the default scene
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.Update(pt.CameraData())                    # unchanged camera: clears the reference-style flag
+        for _ in range(spp):
+            tr.BeginDrawing()
+            tr.Update(pt.CameraData())
+            tr.FinalizeDrawing()
+        img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+    assert st.frames == spp
+    assert_bit_equal(img, ref, name)
+    assert np.array_equal(rng, ref_rng)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("depth", [1, 2])
+def test_statistics_at_the_depth_limit(pt, oracle, name, engine, depth):
+    """A DIFFUSE shade on the last bounce iteration draws its 33 numbers although no ray follows: both engines count it
+    (2 * paths + 33 * diffuse_bounces == draws), sequential and strided."""
+    w, h, spp = 64, 36, 3
+    V, T, M = scenes.all_materials_scene()
+    for strided in (False, True):
+        stride = 2 + 33 * depth
+        ref, _, st_ref, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, rng_mode=1 if strided else 0, stride=stride),
+                                          scene=oracle.make_scene(V, T, M))
+        with pt.PathTracer(w, h) as tr:
+            tr.set_scene(*pt.make_scene(V, T, M))
+            tr.set_options(engine=engine, depth=depth, rng_mode=1 if strided else 0, stride=stride, samples_per_pass=2)
+            tr.render(spp)
+            img, st = tr.readback(), tr.stats()
+        assert_bit_equal(img, ref, f"{name} depth {depth}")
+        assert st.rays == st_ref.rays and st.paths == w * h * spp
+        assert 2 * st.paths + 33 * st.diffuse_bounces == st_ref.draws, (name, depth, strided, st.diffuse_bounces)
+
+
+def test_blob_keeps_its_bvh_decision_when_the_threshold_moves(pt, oracle):
+    """A scene packed while the BVH threshold was lifted (brute force) and rendered after it is back to 512, and the other
+    way round: the launchers dispatch on what the blob carries, not on the process-wide knob."""
+    V, T, M = scenes.synthetic_scene(1100)
+    w, h, spp = 64, 40, 2
+    ref, _, st_ref, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
+    lib = pt.load_library()
+    for packed_under, rendered_under in ((0xFFFFFFFF, 512), (512, 0xFFFFFFFF)):
+        for name, engine in ENGINES:
+            try:
+                with pt.PathTracer(w, h) as tr:
+                    lib.pt_hip_set_bvh_threshold(packed_under)
+                    tr.set_scene(*pt.make_scene(V, T, M))
+                    lib.pt_hip_set_bvh_threshold(rendered_under)
+                    tr.set_options(engine=engine)
+                    tr.render(spp)
+                    img, st = tr.readback(), tr.stats()
+            finally:
+                lib.pt_hip_set_bvh_threshold(512)
+            assert_bit_equal(img, ref, f"{name} packed under {packed_under:#x}, rendered under {rendered_under:#x}")
+            assert st.rays == st_ref.rays
+
+
+def test_create_leaves_the_callers_device_alone(pt):
+    """Every method binds the instance's device for its own duration only (DeviceScope): the calling thread's current
+    device is what it was, before and after."""
+    import ctypes as C
+    lib = pt.load_library()
+    before = C.c_int(-1)
+    assert lib.pt_hip_get_device(C.byref(before)) == 0
+    with pt.PathTracer(32, 16, device=0) as tr:
+        tr.render(1)
+        tr.Resize(16, 16)
+        tr.render(1)
+        assert tr.get_options().device == 0
+        after = C.c_int(-1)
+        assert lib.pt_hip_get_device(C.byref(after)) == 0 and after.value == before.value
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_brute_force_scene_at_the_lds_limit(pt, oracle, name, engine, brute_force_only):
+    """1536 triangles with 256 materials, no BVH: triangles + materials + camera-ray records pass the 160 KiB of a CU, so
+    the wavefront engine must fall back from its one-launch pass to the staged pipeline instead of failing the launch."""
+    V, T, M = scenes.synthetic_scene(1800)          # 1728 triangles (whole quads per face); the first 1536 of them
+    T = T[:1536]
+    assert len(T) == 1536
+    M = [(M[k % len(M)][0], tuple(np.float32(c * (0.9 + 0.0003 * k)) for c in M[k % len(M)][1])) for k in range(256)]
+    T = [(a, b, c, (m + 6 * (k % 42)) % 256) for k, (a, b, c, m) in enumerate(T)]
+    w, h, spp = 48, 30, 2
+    ref, _, st_ref, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine)
+        tr.render(spp)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, ref, name)
+    assert st.rays == st_ref.rays
