@@ -216,6 +216,20 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
                             uint32_t samples_per_pass, uint32_t* rng, void* mean,
                             void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
 
+/* No counterpart in the reference.  pt_hip_render_wavefront for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments minus the workspace, same
+ * results bit for bit; the queues live in a static device array of PT_NOALLOC_SCRATCH_BYTES inside the library (one
+ * copy per GPU the library runs on, held until the process ends).  Calls no hipMalloc / hipFree.  Returns PT_ERR_LIMIT
+ * when pt_hip_wavefront_workspace_bytes(pixel_count, samples in flight, depth) exceeds that size (640x480 at one
+ * sample per pass needs 42 MiB; samples in flight = 1 with PT_RNG_SEQUENTIAL, min(samples_per_pass, n_samples) with
+ * PT_RNG_STRIDED).  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two
+ * threads) race -- serialise them.  The first call on a device looks the array's address up (hipGetSymbolAddress):
+ * make it outside any graph capture. */
+#define PT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int pt_hip_render_wavefront_noalloc(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                                    uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                                    uint32_t samples_per_pass, uint32_t* rng, void* mean, uint64_t* stats, void* stream);
+
 /* The same samples with the whole recurrence of one pixel kept in registers (one lane per
  * pixel, samples in order; no queues, no HBM traffic between stages).  Same results, bit for
  * bit, as pt_hip_render_wavefront. */

@@ -28,6 +28,7 @@ PT_FRAME_FAST_DIV = 1
 PT_FRAME_SCENE_BVH = 2
 PT_MAX_DEPTH = 32
 PT_STATS_WORDS = 4 + PT_MAX_DEPTH
+PT_NOALLOC_SCRATCH_BYTES = 64 << 20
 
 
 class PathTracerError(RuntimeError):
@@ -149,6 +150,7 @@ SYMBOLS = {
     "pt_hip_accumulate": (C.c_int, [_U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "pt_hip_wavefront_workspace_bytes": (_SZ, [_U32, _U32, _U32]),
     "pt_hip_render_wavefront": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _SZ, _VP, _VP]),
+    "pt_hip_render_wavefront_noalloc": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "pt_hip_render_fused": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "pt_hip_combine_shards": (C.c_int, [_VP, _U32, _SZ, _VP, _VP]),
 }

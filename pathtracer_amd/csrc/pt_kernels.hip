@@ -51,6 +51,10 @@ __device__ __forceinline__ void stage_jump31(uint32_t* s_jump) {
 	for (uint32_t k = threadIdx.x; k < 1024u; k += kBlock) s_jump[k] = g[k];
 }
 
+// Queues of pt_hip_render_wavefront_noalloc: one copy per GPU the library runs on, held until the process ends.
+// In host code this name is only a handle for hipGetSymbolAddress (scratch_of_current_device), never an address.
+static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_SCRATCH_BYTES];
+
 thread_local std::string t_last_error;
 
 int fail(pt_status code, const std::string& msg) {
@@ -1019,6 +1023,47 @@ int pt_hip_render_wavefront(const pt_frame* frame, const void* scene_blob, uint3
                             void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream) {
 	return render_wavefront_impl(frame, scene_blob, n_triangles, n_materials, frame_first, mean_first, n_samples, samples_per_pass,
 	                             rng, mean, workspace, workspace_bytes, stats, stream);
+}
+
+// The same render with the queues in the library's own static device array: no hipMalloc / hipFree anywhere on this
+// path (callers under HIP graph capture, serving loops, harnesses that forbid allocation).  `scratch` is a HOST-side
+// stand-in for the device array -- never a device address: the address on the current device comes from
+// hipGetSymbolAddress, once per device, and only that pointer is handed to kernels and memsets.
+static int scratch_of_current_device(unsigned char** out) {
+	constexpr int kMaxDevices = 64;
+	static std::mutex mu;
+	static unsigned char* ptrs[kMaxDevices] = {};
+	int dev = -1;
+	HIP_TRY(hipGetDevice(&dev));
+	if (dev < 0 || dev >= kMaxDevices) return fail(PT_ERR_LIMIT, "render_wavefront_noalloc: device ordinal beyond 63");
+	std::lock_guard<std::mutex> lock(mu);
+	if (!ptrs[dev]) {
+		void* p = nullptr;
+		HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));       // this device's copy of the array
+		if (!p) return fail(PT_ERR_HIP, "render_wavefront_noalloc: hipGetSymbolAddress returned null");
+		ptrs[dev] = (unsigned char*)p;
+	}
+	*out = ptrs[dev];
+	return PT_OK;
+}
+
+int pt_hip_render_wavefront_noalloc(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                                    uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
+                                    uint32_t samples_per_pass, uint32_t* rng, void* mean, uint64_t* stats, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (n_samples == 0 || frame->pixel_count == 0) return PT_OK;
+	// what render_wavefront_impl will carve: SEQUENTIAL keeps one sample per pixel in flight whatever samples_per_pass is
+	uint32_t in_flight = frame->rng_mode == PT_RNG_SEQUENTIAL ? 1u : std::min(std::max(samples_per_pass, 1u), n_samples);
+	Workspace w;
+	size_t need = carve(&w, nullptr, frame->pixel_count, in_flight);
+	if (need > (size_t)PT_NOALLOC_SCRATCH_BYTES)
+		return fail(PT_ERR_LIMIT, "render_wavefront_noalloc: " + std::to_string(frame->pixel_count) + " pixels x " + std::to_string(in_flight) +
+		            " samples in flight need " + std::to_string(need) + " bytes of queues, the static scratch holds " +
+		            std::to_string((size_t)PT_NOALLOC_SCRATCH_BYTES) + " (use pt_hip_render_wavefront with a workspace of your own)");
+	unsigned char* ws = nullptr;
+	if (int rc = scratch_of_current_device(&ws)) return rc;
+	return render_wavefront_impl(frame, scene_blob, n_triangles, n_materials, frame_first, mean_first, n_samples, samples_per_pass,
+	                             rng, mean, ws, (size_t)PT_NOALLOC_SCRATCH_BYTES, stats, stream);
 }
 
 int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
