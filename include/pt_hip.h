@@ -67,7 +67,7 @@ enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
 #define PT_FRAME_SCENE_BVH 2u
 
 /* Which kernels execute a render call. */
-enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1 };
+enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1, PT_ENGINE_AUTO = 2 };     /* AUTO: pt_plugin.h (the plugin measures and picks) */
 
 #define PT_MAX_DEPTH 32
 #define PT_DEFAULT_DEPTH 10      /* PathTracer.cu:129 */
@@ -106,6 +106,8 @@ int pt_hip_free(void* device_ptr);
 int pt_hip_memcpy_h2d(void* device_dst, const void* host_src, size_t bytes, void* stream);
 int pt_hip_memcpy_d2h(void* host_dst, const void* device_src, size_t bytes, void* stream);
 int pt_hip_memcpy_d2d(void* device_dst, const void* device_src, size_t bytes, void* stream);   /* asynchronous */
+/* device-to-device across GPUs of this process (over xGMI when peer access is possible, staged otherwise); asynchronous */
+int pt_hip_memcpy_peer(void* device_dst, int dst_device, const void* device_src, int src_device, size_t bytes, void* stream);
 int pt_hip_memset(void* device_dst, int byte_value, size_t bytes, void* stream);
 int pt_hip_fill_f32(float* device_dst, float value, size_t count, void* stream);
 int pt_hip_stream_create(void** stream);
@@ -241,6 +243,23 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
  * out = (fixed-order pairwise tree sum of `shards` means laid out shard-major) * 1/shards. */
 int pt_hip_combine_shards(const void* shard_means, uint32_t shards, size_t n_pixels,
                           void* out, void* stream);
+
+/* ---- sample split across GPUs over RCCL (no reference counterpart: the reference is single-GPU, PathTracer.cu:25).
+ * librccl is loaded on first use (dlopen), so the library also loads where RCCL is absent; these calls then return
+ * PT_ERR_STATE.  One communicator per instance (= per GPU), created on the calling thread's current device.
+ * id128: the 128 bytes of an ncclUniqueId, made on one rank and handed to the others by the host's own means. */
+int pt_hip_comm_unique_id(void* id128);
+int pt_hip_comm_create(void** comm, const void* id128, int rank, int ranks);
+int pt_hip_comm_destroy(void* comm);
+int pt_hip_comm_ranks(void* comm, int* ranks);
+/* The one exchange of a sample-split render, enqueued on `stream`.  This rank (`rank` of `ranks`) holds `local`
+ * shard means of `pitch_pixels` float4 each (pitch_pixels = ranks * slice_pixels; local shard j is virtual shard
+ * rank + j*ranks).  (1) slice r of every local shard goes to rank r and `stacked` (local*ranks shards x slice_pixels
+ * float4, shard-major in virtual-shard order) receives this rank's slice of every shard: grouped ncclSend/ncclRecv, every
+ * xGMI link busy at once; (2) the fixed-order tree of pt_hip_combine_shards over the local*ranks shards into
+ * image[rank*slice_pixels ..]; (3) ncclAllGather in place: every rank ends with the whole image (pitch_pixels float4). */
+int pt_hip_comm_exchange_combine(void* comm, int rank, int ranks, const void* local_shards, uint32_t local,
+                                 size_t slice_pixels, void* stacked, void* image, void* stream);
 
 #ifdef __cplusplus
 }

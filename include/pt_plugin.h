@@ -38,7 +38,7 @@ typedef struct {
 } pt_camera_data;
 
 typedef struct {
-    uint32_t engine;             /* PT_ENGINE_FUSED (default) or PT_ENGINE_WAVEFRONT */
+    uint32_t engine;             /* PT_ENGINE_AUTO (default: probes both, keeps the faster; same bits either way), PT_ENGINE_FUSED or PT_ENGINE_WAVEFRONT */
     uint32_t rng_mode;           /* PT_RNG_SEQUENTIAL (default, the reference) or PT_RNG_STRIDED */
     uint32_t stride;             /* STRIDED: draws reserved per sample (default 35) */
     uint32_t depth;              /* bounce iterations, default 10 (PathTracer.cu:129) */
@@ -50,7 +50,24 @@ typedef struct {
     uint32_t pixel_count;        /* 0 = the whole image */
     uint32_t sample_offset;      /* STRIDED sample split: RNG index of this instance's first sample */
     uint32_t shading;            /* PT_SHADING_REFERENCE (default) or PT_SHADING_EXTENDED (pt_hip.h) */
+    /* Multi-GPU split of one frame over `split_ranks` instances, one per GPU (no reference counterpart: single device,
+     * PathTracer.cu:25).  This instance is number `split_rank`.
+     * PT_SPLIT_TILE: the instance renders pixels [n*rank/ranks, n*(rank+1)/ranks) with the reference's sequential streams;
+     *   the tiles put side by side ARE the single-GPU image, bit for bit (pixel_first/pixel_count are derived).
+     * PT_SPLIT_SAMPLE (needs PT_RNG_STRIDED): the frame's samples are dealt to `virtual_shards` shards (V, default 8, a
+     *   power of two <= 16, whatever the GPU count); shard v takes the RNG sample indices sample_offset + v*PT_SHARD_SPAN + k
+     *   and has a running mean of its own; this instance renders the shards {v : v % ranks == rank} (ranks must divide V),
+     *   one BeginDrawing adds samples_per_begin samples to EACH of them.  The image is the fixed-order pairwise tree over
+     *   the V shard means times 1/V (pt_combine_instances / pt_dist_combine): the same bits on 1, 2, 4 or 8 GPUs. */
+    uint32_t split_mode;         /* PT_SPLIT_NONE (default) / PT_SPLIT_TILE / PT_SPLIT_SAMPLE */
+    uint32_t split_rank;
+    uint32_t split_ranks;        /* 0 or 1 = a single instance */
+    uint32_t virtual_shards;     /* SAMPLE: V; 0 = PT_VIRTUAL_SHARDS */
 } pt_options;
+
+enum { PT_SPLIT_NONE = 0, PT_SPLIT_TILE = 1, PT_SPLIT_SAMPLE = 2 };
+#define PT_VIRTUAL_SHARDS 8u
+#define PT_SHARD_SPAN (1u << 20)     /* RNG sample indices reserved per virtual shard: at most 2^20 samples per shard */
 
 typedef struct {
     uint64_t rays;               /* extend-stage work items since the last restart */
@@ -61,6 +78,9 @@ typedef struct {
     double   last_render_ms;     /* device time of the last finalized BeginDrawing/pt_render */
     double   total_render_ms;    /* sum of the above since the last restart (HIP events on the plugin's stream) */
     uint64_t renders;            /* finalized BeginDrawing/pt_render submissions since the last restart */
+    uint32_t engine_in_use;      /* the engine option, or under PT_ENGINE_AUTO: the engine chosen (PT_ENGINE_AUTO while still probing) */
+    uint32_t _pad;
+    double   auto_rays_per_ms[2];/* PT_ENGINE_AUTO: what the probes measured, indexed by engine (0 = not probed yet) */
 } pt_stats;
 
 const char* pt_last_error(void);
@@ -113,6 +133,27 @@ void* pt_stream(pt_handle* h);
 /* Device address of the running mean (float4 x pixel_count), for collectives and zero-copy. */
 void* pt_device_mean(pt_handle* h);
 int pt_get_stats(pt_handle* h, pt_stats* out);
+
+/* ---- sample split: combining the shards (PT_SPLIT_SAMPLE).  After a combine, pt_readback / pt_copy_mean of the instance
+ * that holds the result return the IMAGE (pixel_count float4); pt_device_mean stays the instance's own shard means
+ * (local shards x pitch float4, see pt_get_shard_layout).  A single instance (split_ranks <= 1) combines by itself on
+ * pt_readback.
+ *
+ * Same process, one instance per GPU (or several on one GPU), driven from any threads: pt_combine_instances gathers
+ * the shard means of all `n` instances onto handles[0]'s GPU (peer copies over xGMI) and runs the tree there; the
+ * handles must be the split_ranks instances of one split, in any order.  Call it from one thread after the renders. */
+int pt_combine_instances(pt_handle* const* handles, uint32_t n);
+/* One process per GPU (or one thread per GPU) over RCCL: rank 0 makes an id (128 bytes) and hands it to the others by
+ * its own means (a file, MPI, torch.distributed's store ..), every rank calls pt_dist_init (collective), then
+ * pt_dist_combine after its renders (collective, one exchange: all-to-all of image slices, tree on the own slice,
+ * all-gather): every rank then holds the whole image. */
+int pt_dist_unique_id(void* id128);
+int pt_dist_init(pt_handle* h, const void* id128);
+int pt_dist_combine(pt_handle* h);
+/* local shards of this instance, the pitch (in pixels) between their means, and the number of virtual shards */
+int pt_get_shard_layout(pt_handle* h, uint32_t* local_shards, uint32_t* pitch_pixels, uint32_t* virtual_shards);
+/* Thread-safe Create on a given device (pt_set_default_device + Create is process-global state): device < 0 = current. */
+pt_handle* pt_create_on_device(int device, int pixel_width, int pixel_height, const pt_camera_data* camera);
 int pt_get_size(pt_handle* h, int* width, int* height, uint32_t* pixel_first, uint32_t* pixel_count);
 
 #ifdef __cplusplus

@@ -476,22 +476,34 @@ int pto_render_sharded(const pto_render_params *p, uint32_t shards,
                        const uint32_t *pixel_ids, uint32_t pixel_first, uint32_t n,
                        pto_f4 *mean, pto_stats *stats)
 {
+    return pto_render_sharded_span(p, shards, shards ? p->spp / shards : 0, verts, n_verts, tris, n_tris, mats, n_mats,
+                                   pixel_ids, pixel_first, n, mean, stats);
+}
+
+int pto_render_sharded_span(const pto_render_params *p, uint32_t shards, uint32_t span,
+                            const pto_vertex *verts, uint32_t n_verts,
+                            const pto_triangle *tris, uint32_t n_tris,
+                            const pto_material *mats, uint32_t n_mats,
+                            const uint32_t *pixel_ids, uint32_t pixel_first, uint32_t n,
+                            pto_f4 *mean, pto_stats *stats)
+{
     if (p->rng_mode != PTO_RNG_STRIDED) return -5;
     if (shards == 0 || shards > 64 || (shards & (shards - 1)) || p->spp % shards) return -6;
     pto_f4 *buf = (pto_f4 *)malloc((size_t)shards * n * sizeof(pto_f4));
     if (!buf) return -7;
     pto_stats total; memset(&total, 0, sizeof(total));
     uint32_t per = p->spp / shards;
+    if (span < per) return -6;                       /* shards would share samples */
     int rc = 0;
     for (uint32_t v = 0; v < shards && rc == 0; v++) {
         pto_f4 *m = buf + (size_t)v * n;
         for (size_t k = 0; k < n; k++) m[k] = f4(1.0f, 1.0f, 1.0f, 1.0f);  /* white start, Surface.cpp:99-115 */
         pto_stats st;
-        /* shard v renders samples [frame_first + v*per, +per) but accumulates from frameNumber 0 */
+        /* shard v renders samples [frame_first + v*span, +per) but accumulates from frameNumber 0 */
         for (uint32_t s = 0; s < per && rc == 0; s++) {
             pto_render_params q = *p;
             q.spp = 1;
-            q.frame_first = p->frame_first + v * per + s;
+            q.frame_first = p->frame_first + v * span + s;
             /* one sample at a time so the RNG index and the mean index can differ */
             pto_f4 *frame = (pto_f4 *)malloc(n * sizeof(pto_f4));
             pto_f4 *scratch = (pto_f4 *)malloc(n * sizeof(pto_f4));

@@ -154,6 +154,16 @@ int pto_render_sharded(const pto_render_params *p, uint32_t shards,
                        const uint32_t *pixel_ids, uint32_t pixel_first, uint32_t n,
                        pto_f4 *mean, pto_stats *stats);
 
+/* The same with shard v on the RNG sample indices frame_first + v*span + s, s < spp/shards (span >= spp/shards): the
+ * virtual shards of include/pt_plugin.h (PT_SPLIT_SAMPLE, span = PT_SHARD_SPAN), whose image does not depend on how
+ * many GPUs render them.  pto_render_sharded is span = spp/shards. */
+int pto_render_sharded_span(const pto_render_params *p, uint32_t shards, uint32_t span,
+                            const pto_vertex *verts, uint32_t n_verts,
+                            const pto_triangle *tris, uint32_t n_tris,
+                            const pto_material *mats, uint32_t n_mats,
+                            const uint32_t *pixel_ids, uint32_t pixel_first, uint32_t n,
+                            pto_f4 *mean, pto_stats *stats);
+
 /* fixed-order pairwise tree combine of `shards` (power of two) means, then * 1/shards */
 void pto_combine_shards(const pto_f4 *shard_means, uint32_t shards, size_t n, pto_f4 *out);
 

@@ -103,6 +103,9 @@ def lib() -> C.CDLL:
         L.pto_render_sharded.restype = C.c_int
         L.pto_render_sharded.argtypes = [C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                          C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+        L.pto_render_sharded_span.restype = C.c_int
+        L.pto_render_sharded_span.argtypes = [C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         L.pto_combine_shards.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
@@ -195,7 +198,8 @@ def render(p: RenderParams, scene=None, pixel_first=0, n=None, pixel_ids=None, r
     return mean, rng_states, st, last
 
 
-def render_sharded(p: RenderParams, shards: int, scene=None, pixel_first=0, n=None, pixel_ids=None):
+def render_sharded(p: RenderParams, shards: int, scene=None, pixel_first=0, n=None, pixel_ids=None, span=None):
+    """span: RNG sample indices between the starts of two shards (None: spp/shards, the shards back to back)"""
     v, t, m = scene or default_scene()
     ids = None
     if pixel_ids is not None:
@@ -205,9 +209,10 @@ def render_sharded(p: RenderParams, shards: int, scene=None, pixel_first=0, n=No
         n = p.width * p.height - pixel_first
     mean = np.empty((n, 4), dtype=np.float32)
     st = Stats()
-    rc = lib().pto_render_sharded(C.byref(p), shards, C.cast(v, C.c_void_p), len(v), C.cast(t, C.c_void_p), len(t),
-                                  C.cast(m, C.c_void_p), len(m), ids.ctypes.data if ids is not None else None, pixel_first, n,
-                                  mean.ctypes.data, C.byref(st))
+    rc = lib().pto_render_sharded_span(C.byref(p), shards, p.spp // shards if span is None else span,
+                                       C.cast(v, C.c_void_p), len(v), C.cast(t, C.c_void_p), len(t),
+                                       C.cast(m, C.c_void_p), len(m), ids.ctypes.data if ids is not None else None, pixel_first, n,
+                                       mean.ctypes.data, C.byref(st))
     if rc != 0:
         raise RuntimeError(f"pto_render_sharded failed: {rc}")
     return mean, st

@@ -21,7 +21,10 @@ LIBRARY_PATH = os.path.join(_HERE, LIBRARY_NAME)
 
 PT_OK = 0
 PT_RNG_SEQUENTIAL, PT_RNG_STRIDED = 0, 1
-PT_ENGINE_WAVEFRONT, PT_ENGINE_FUSED = 0, 1
+PT_ENGINE_WAVEFRONT, PT_ENGINE_FUSED, PT_ENGINE_AUTO = 0, 1, 2
+PT_SPLIT_NONE, PT_SPLIT_TILE, PT_SPLIT_SAMPLE = 0, 1, 2
+PT_VIRTUAL_SHARDS = 8
+PT_SHARD_SPAN = 1 << 20
 PT_MAT_DIFFUSE, PT_MAT_REFLECTIVE, PT_MAT_EMISSIVE = 0, 1, 2
 PT_SHADING_REFERENCE, PT_SHADING_EXTENDED = 0, 1
 PT_FRAME_FAST_DIV = 1
@@ -77,13 +80,15 @@ class Options(C.Structure):
     _fields_ = [("engine", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32), ("depth", C.c_uint32),
                 ("seed", C.c_uint32), ("samples_per_begin", C.c_uint32), ("samples_per_pass", C.c_uint32),
                 ("device", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
-                ("sample_offset", C.c_uint32), ("shading", C.c_uint32)]
+                ("sample_offset", C.c_uint32), ("shading", C.c_uint32),
+                ("split_mode", C.c_uint32), ("split_rank", C.c_uint32), ("split_ranks", C.c_uint32), ("virtual_shards", C.c_uint32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("diffuse_bounces", C.c_uint64), ("paths", C.c_uint64), ("frames", C.c_uint64),
                 ("rays_per_bounce", C.c_uint64 * PT_MAX_DEPTH), ("last_render_ms", C.c_double),
-                ("total_render_ms", C.c_double), ("renders", C.c_uint64)]
+                ("total_render_ms", C.c_double), ("renders", C.c_uint64),
+                ("engine_in_use", C.c_uint32), ("_pad", C.c_uint32), ("auto_rays_per_ms", C.c_double * 2)]
 
 
 assert C.sizeof(Vertex) == 16 and C.sizeof(Triangle) == 16 and C.sizeof(Material) == 48 and C.sizeof(CameraData) == 36
@@ -118,6 +123,12 @@ SYMBOLS = {
     "pt_device_mean": (_VP, [_VP]),
     "pt_get_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
     "pt_get_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), _U32P, _U32P]),
+    "pt_combine_instances": (C.c_int, [C.POINTER(_VP), _U32]),
+    "pt_dist_unique_id": (C.c_int, [_VP]),
+    "pt_dist_init": (C.c_int, [_VP, _VP]),
+    "pt_dist_combine": (C.c_int, [_VP]),
+    "pt_get_shard_layout": (C.c_int, [_VP, _U32P, _U32P, _U32P]),
+    "pt_create_on_device": (_VP, [C.c_int, C.c_int, C.c_int, C.POINTER(CameraData)]),
     # pt_hip.h
     "pt_hip_last_error": (C.c_char_p, []),
     "pt_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -128,6 +139,7 @@ SYMBOLS = {
     "pt_hip_memcpy_h2d": (C.c_int, [_VP, _VP, _SZ, _VP]),
     "pt_hip_memcpy_d2h": (C.c_int, [_VP, _VP, _SZ, _VP]),
     "pt_hip_memcpy_d2d": (C.c_int, [_VP, _VP, _SZ, _VP]),
+    "pt_hip_memcpy_peer": (C.c_int, [_VP, C.c_int, _VP, C.c_int, _SZ, _VP]),
     "pt_hip_memset": (C.c_int, [_VP, C.c_int, _SZ, _VP]),
     "pt_hip_fill_f32": (C.c_int, [_VP, C.c_float, _SZ, _VP]),
     "pt_hip_stream_create": (C.c_int, [C.POINTER(_VP)]),
@@ -153,6 +165,11 @@ SYMBOLS = {
     "pt_hip_render_wavefront_noalloc": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "pt_hip_render_fused": (C.c_int, [_FRAMEP, _VP, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "pt_hip_combine_shards": (C.c_int, [_VP, _U32, _SZ, _VP, _VP]),
+    "pt_hip_comm_unique_id": (C.c_int, [_VP]),
+    "pt_hip_comm_create": (C.c_int, [C.POINTER(_VP), _VP, C.c_int, C.c_int]),
+    "pt_hip_comm_destroy": (C.c_int, [_VP]),
+    "pt_hip_comm_ranks": (C.c_int, [_VP, C.POINTER(C.c_int)]),
+    "pt_hip_comm_exchange_combine": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _U32, _SZ, _VP, _VP, _VP]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -242,10 +259,9 @@ class PathTracer:
         self._lib = load_library(library)
         self._camera = camera or CameraData()
         if device is not None:
-            self._lib.pt_set_default_device(int(device))
-        self._h = self._lib.Create(0, int(width), int(height), C.byref(self._camera))
-        if device is not None:
-            self._lib.pt_set_default_device(-1)
+            self._h = self._lib.pt_create_on_device(int(device), int(width), int(height), C.byref(self._camera))
+        else:
+            self._h = self._lib.Create(0, int(width), int(height), C.byref(self._camera))     # the reference's export
         if not self._h:
             raise PathTracerError("Create failed: " + (self._lib.pt_last_error() or b"").decode(errors="replace"))
 
@@ -339,11 +355,40 @@ class PathTracer:
     def device_mean(self) -> int:
         return int(self._lib.pt_device_mean(self._h) or 0)
 
+    # -- sample split (include/pt_plugin.h) --
+    def shard_layout(self):
+        """(local shards, pitch in pixels between their means, virtual shards)"""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(self._lib.pt_get_shard_layout(self._h, C.byref(a), C.byref(b), C.byref(c)), self._lib, "pt_get_shard_layout")
+        return a.value, b.value, c.value
+
+    def dist_init(self, id128: bytes) -> None:
+        buf = C.create_string_buffer(bytes(id128), 128)
+        _check(self._lib.pt_dist_init(self._h, C.cast(buf, C.c_void_p)), self._lib, "pt_dist_init")
+
+    def dist_combine(self) -> None:
+        _check(self._lib.pt_dist_combine(self._h), self._lib, "pt_dist_combine")
+
     def stats(self) -> Stats:
         s = Stats()
         _check(self._lib.pt_get_stats(self._h, C.byref(s)), self._lib, "pt_get_stats")
         return s
 
 
-__all__ = ["PathTracer", "PathTracerError", "CameraData", "Options", "Stats", "Frame", "Queue", "Float4", "Vertex",
+def dist_unique_id() -> bytes:
+    """128 bytes of an ncclUniqueId (rank 0 makes it, the others get it by the host's own means)."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    _check(lib.pt_dist_unique_id(C.cast(buf, C.c_void_p)), lib, "pt_dist_unique_id")
+    return buf.raw
+
+
+def combine_instances(tracers) -> None:
+    """pt_combine_instances: all instances of one sample split, in this process; the image lands in tracers[0]."""
+    lib = load_library()
+    arr = (C.c_void_p * len(tracers))(*[t._h for t in tracers])
+    _check(lib.pt_combine_instances(arr, len(tracers)), lib, "pt_combine_instances")
+
+
+__all__ = ["PathTracer", "dist_unique_id", "combine_instances", "PathTracerError", "CameraData", "Options", "Stats", "Frame", "Queue", "Float4", "Vertex",
            "Triangle", "Material", "load_library", "default_scene", "make_scene", "SYMBOLS", "LIBRARY_PATH"]

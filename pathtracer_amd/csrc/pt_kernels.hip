@@ -12,6 +12,7 @@
 // reset kernels and no host synchronisation inside a pass.  The scene is packed once and staged
 // in LDS by every block.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -675,6 +676,13 @@ int pt_hip_memcpy_d2d(void* d, const void* src, size_t bytes, void* stream) {
 	HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
 	return PT_OK;
 }
+int pt_hip_memcpy_peer(void* d, int dst_device, const void* src, int src_device, size_t bytes, void* stream) {
+	if (bytes == 0) return PT_OK;
+	if (!d || !src) return fail(PT_ERR_INVALID, "memcpy_peer: null pointer");
+	if (dst_device == src_device) HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+	else HIP_TRY(hipMemcpyPeerAsync(d, dst_device, src, src_device, bytes, (hipStream_t)stream));
+	return PT_OK;
+}
 int pt_hip_memset(void* d, int byte_value, size_t bytes, void* stream) {
 	if (bytes == 0) return PT_OK;
 	if (!d) return fail(PT_ERR_INVALID, "memset: null pointer");
@@ -1119,6 +1127,126 @@ int pt_hip_combine_shards(const void* shard_means, uint32_t shards, size_t n_pix
 	default: return fail(PT_ERR_LIMIT, "combine_shards: at most 16 shards");     // not reached: checked above
 	}
 	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+} // extern "C"
+
+// ---- RCCL, loaded on first use.  Only the handful of calls the exchange needs; types as in rccl/rccl.h.
+namespace {
+struct RcclUniqueId { char internal[128]; };
+typedef void* RcclComm;
+constexpr int kNcclFloat = 7;       // ncclFloat32
+struct Rccl {
+	void* handle = nullptr;
+	int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+	int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+	int (*CommDestroy)(RcclComm) = nullptr;
+	int (*CommCount)(RcclComm, int*) = nullptr;
+	int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+	std::string error;
+};
+const Rccl& rccl() {
+	static const Rccl* lib = [] {
+		Rccl* r = new Rccl;
+		// a process that already holds an RCCL (torch ships its own) gets that one back by soname
+		for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" }) {
+			r->handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (r->handle) break;
+		}
+		if (!r->handle) { r->error = std::string("librccl not found: ") + dlerror(); return r; }
+		bool ok = true;
+		auto sym = [&](const char* n) { void* p = dlsym(r->handle, n); if (!p) { ok = false; r->error = std::string("librccl lacks ") + n; } return p; };
+		r->GetUniqueId = (decltype(r->GetUniqueId))sym("ncclGetUniqueId");
+		r->CommInitRank = (decltype(r->CommInitRank))sym("ncclCommInitRank");
+		r->CommDestroy = (decltype(r->CommDestroy))sym("ncclCommDestroy");
+		r->CommCount = (decltype(r->CommCount))sym("ncclCommCount");
+		r->Send = (decltype(r->Send))sym("ncclSend");
+		r->Recv = (decltype(r->Recv))sym("ncclRecv");
+		r->AllGather = (decltype(r->AllGather))sym("ncclAllGather");
+		r->GroupStart = (decltype(r->GroupStart))sym("ncclGroupStart");
+		r->GroupEnd = (decltype(r->GroupEnd))sym("ncclGroupEnd");
+		r->GetErrorString = (decltype(r->GetErrorString))sym("ncclGetErrorString");
+		if (!ok) { dlclose(r->handle); r->handle = nullptr; }
+		return r;
+	}();
+	return *lib;
+}
+int rccl_fail(int code, const char* what) {
+	return fail(PT_ERR_HIP, std::string(what) + ": RCCL error " + std::to_string(code) + " (" + (rccl().GetErrorString ? rccl().GetErrorString(code) : "?") + ")");
+}
+#define RCCL_READY() do { if (!rccl().handle) return fail(PT_ERR_STATE, rccl().error); } while (0)
+#define RCCL_TRY(expr) do { int e_ = (expr); if (e_ != 0) return rccl_fail(e_, #expr); } while (0)
+} // namespace
+
+extern "C" {
+
+int pt_hip_comm_unique_id(void* id128) {
+	if (!id128) return fail(PT_ERR_INVALID, "comm_unique_id: null pointer");
+	RCCL_READY();
+	RcclUniqueId id;
+	RCCL_TRY(rccl().GetUniqueId(&id));
+	std::memcpy(id128, &id, sizeof(id));
+	return PT_OK;
+}
+int pt_hip_comm_create(void** comm, const void* id128, int rank, int ranks) {
+	if (!comm || !id128) return fail(PT_ERR_INVALID, "comm_create: null pointer");
+	if (ranks < 1 || rank < 0 || rank >= ranks) return fail(PT_ERR_INVALID, "comm_create: rank must be in [0, ranks)");
+	RCCL_READY();
+	RcclUniqueId id;
+	std::memcpy(&id, id128, sizeof(id));
+	RcclComm c = nullptr;
+	RCCL_TRY(rccl().CommInitRank(&c, ranks, id, rank));
+	*comm = c;
+	return PT_OK;
+}
+int pt_hip_comm_destroy(void* comm) {
+	if (!comm) return PT_OK;
+	RCCL_READY();
+	RCCL_TRY(rccl().CommDestroy((RcclComm)comm));
+	return PT_OK;
+}
+int pt_hip_comm_ranks(void* comm, int* ranks) {
+	if (!comm || !ranks) return fail(PT_ERR_INVALID, "comm_ranks: null pointer");
+	RCCL_READY();
+	RCCL_TRY(rccl().CommCount((RcclComm)comm, ranks));
+	return PT_OK;
+}
+int pt_hip_comm_exchange_combine(void* comm, int rank, int ranks, const void* local_shards, uint32_t local,
+                                 size_t slice_pixels, void* stacked, void* image, void* stream) {
+	if (!local_shards || !stacked || !image) return fail(PT_ERR_INVALID, "comm_exchange_combine: null pointer");
+	if (ranks < 1 || rank < 0 || rank >= ranks || local == 0) return fail(PT_ERR_INVALID, "comm_exchange_combine: bad rank / ranks / local");
+	if (!comm && ranks > 1) return fail(PT_ERR_STATE, "comm_exchange_combine: more than one rank needs a communicator");
+	hipStream_t s = (hipStream_t)stream;
+	const size_t slice_floats = slice_pixels * 4, pitch_floats = slice_floats * (size_t)ranks;
+	const float* src = (const float*)local_shards;
+	float* st = (float*)stacked;
+	if (!comm) {
+		// the only rank owns every shard: they already are shard-major (no communicator needed)
+		st = const_cast<float*>(src);
+	} else {
+		RCCL_READY();
+		int count = 0;
+		RCCL_TRY(rccl().CommCount((RcclComm)comm, &count));
+		if (count != ranks) return fail(PT_ERR_INVALID, "comm_exchange_combine: the communicator has " + std::to_string(count) + " ranks, not " + std::to_string(ranks));
+		RCCL_TRY(rccl().GroupStart());
+		for (uint32_t j = 0; j < local; j++)
+			for (int r = 0; r < ranks; r++) {
+				// slice r of local shard j (= virtual shard rank + j*ranks) -> rank r; from rank r: my slice of ITS shard r + j*ranks
+				int e1 = rccl().Send(src + (size_t)j * pitch_floats + (size_t)r * slice_floats, slice_floats, kNcclFloat, r, (RcclComm)comm, s);
+				int e2 = rccl().Recv(st + ((size_t)j * ranks + r) * slice_floats, slice_floats, kNcclFloat, r, (RcclComm)comm, s);
+				if (e1 || e2) { rccl().GroupEnd(); return rccl_fail(e1 ? e1 : e2, "ncclSend/ncclRecv"); }
+			}
+		RCCL_TRY(rccl().GroupEnd());
+	}
+	float* mine = (float*)image + (size_t)rank * slice_floats;
+	if (int rc = pt_hip_combine_shards(st, local * (uint32_t)ranks, slice_pixels, mine, stream)) return rc;
+	if (comm) RCCL_TRY(rccl().AllGather(mine, image, slice_floats, kNcclFloat, (RcclComm)comm, s));
 	return PT_OK;
 }
 

@@ -12,6 +12,7 @@
 // Differences, all forced by running headless: no GL texture (the running mean is a device
 // buffer, see pt_readback), no cudaDeviceReset in the destructor (it would tear down other
 // users of the device in the same process), errors are recorded instead of thrown.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -74,37 +75,56 @@ void DefaultScene(std::vector<pt_vertex>& v, std::vector<pt_triangle>& t, std::v
 class PathTracer final : public IPathTracer {
 	int _width, _height;
 	pt::Camera _camera;
-	uint32_t _frameNumber = 0;
+	uint32_t _frameNumber = 0;          // samples in the running mean (SAMPLE split: in each shard's mean)
 	bool _shouldRestartRendering = false;
 	enum DrawState { Idle, Drawing } _drawState = Idle;
 	uint32_t _inFlightSamples = 0;
 
 	pt_options _opt{};
 	uint32_t _pixelFirst = 0, _pixelCount = 0;
+	// sample split (pt_plugin.h): V virtual shards, this instance renders _localShards of them into means `_pitch` pixels
+	// apart (_pitch = ranks * _slice >= _pixelCount, so that the exchange moves whole, equal slices)
+	uint32_t _vShards = 1, _localShards = 1, _ranks = 1, _pitch = 0, _slice = 0;
+	bool _imageCurrent = false;         // _dev.image holds the combine of the shard means as they are now
 
 	struct DevicePtrs {
 		uint32_t* rng = nullptr;        // per-pixel xorshift32 stream (RngState, Structures.cuh:18)
-		void* mean = nullptr;           // float4 running mean: stands in for the GL surface
+		void* mean = nullptr;           // float4 running mean(s): stands in for the GL surface
 		void* scene = nullptr;          // packed Triangle/Vertex/Material blob
 		uint64_t* stats = nullptr;
 		void* workspace = nullptr;      // wavefront queues
+		void* image = nullptr;          // SAMPLE split: the combined image, _pitch float4
+		void* stacked = nullptr;        // SAMPLE split: shard-major staging of a combine (V x slice, or V x pitch on a gather root)
 	} _dev;
-	size_t _workspaceBytes = 0;
+	size_t _workspaceBytes = 0, _stackedBytes = 0;
 	uint32_t _nTris = 0, _nMats = 0;
 	bool _sceneHasBvh = false;          // recorded when the scene is packed (pt_hip_scene_has_bvh), passed with every frame
 	int _device = -1;                   // resolved HIP ordinal of this instance, bound by every method (DeviceScope)
 	void* _stream = nullptr;
 	void* _evStart = nullptr;
 	void* _evStop = nullptr;
+	void* _comm = nullptr;              // RCCL communicator of pt_dist_init
 	double _lastMs = 0.0, _totalMs = 0.0;
 	uint64_t _renders = 0;
 	uint32_t _frameFlags = 0;           // PT_FRAME_FAST_DIV once both image sizes are verified
 	int _error = PT_OK;                 // sticky: once a device call fails the object stops rendering
 
+	// PT_ENGINE_AUTO.  Both engines return the same bits, so which one runs is a matter of speed only, and that depends
+	// on the scene, the image size and the RNG mode in ways no static rule covers (default scene: fused 235 against 203
+	// Grays/s; all-materials scene with strided streams: wavefront 29.7 against 15.7; BVH scenes at 1080p: wavefront
+	// 1.7x, at 64x40 the staged pipeline's 30 launches per sample lose).  So AUTO measures: after a change of scene,
+	// options or size the first render runs fused, the second wavefront, and from the third on the one that traced more
+	// rays per millisecond of device time (HIP events, device ray counters).  A camera restart keeps the decision.
+	enum AutoPhase { ProbeFused, ProbeWavefront, Decided };
+	AutoPhase _autoPhase = ProbeFused;
+	uint32_t _autoChoice = PT_ENGINE_FUSED, _engineInFlight = PT_ENGINE_FUSED;
+	double _autoRate[2] = { 0.0, 0.0 };     // rays per ms, indexed by engine
+	uint64_t _raysBefore = 0;
+
 public:
 	PathTracer(int pixelWidth, int pixelHeight, const CameraData* cameraData)
 		: _width(pixelWidth), _height(pixelHeight), _camera(cameraData, (float)pixelWidth / pixelHeight) {
-		_opt.engine = PT_ENGINE_FUSED;
+		_opt.engine = PT_ENGINE_AUTO;
 		_opt.rng_mode = PT_RNG_SEQUENTIAL;
 		_opt.stride = PT_DEFAULT_STRIDE;
 		_opt.depth = PT_DEFAULT_DEPTH;
@@ -112,6 +132,8 @@ public:
 		_opt.samples_per_begin = 1;
 		_opt.samples_per_pass = 16;
 		_opt.device = -1;
+		_opt.split_ranks = 1;
+		_opt.virtual_shards = PT_VIRTUAL_SHARDS;
 	}
 
 	void SetDevice(int device) { _opt.device = device; }
@@ -141,8 +163,9 @@ public:
 		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		if (_stream) pt_hip_stream_synchronize(_stream);
+		if (_comm) pt_hip_comm_destroy(_comm);
 		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.scene);
-		pt_hip_free(_dev.stats); pt_hip_free(_dev.workspace);
+		pt_hip_free(_dev.stats); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked);
 		pt_hip_event_destroy(_evStart); pt_hip_event_destroy(_evStop);
 		pt_hip_stream_destroy(_stream);
 	}
@@ -175,6 +198,7 @@ public:
 		}
 		if (pt_hip_stream_synchronize(_stream) != PT_OK) { _error = hip_layer_fail(PT_ERR_HIP, "FinalizeDrawing"); return; }
 		_frameNumber += _inFlightSamples;
+		if (_inFlightSamples && _opt.engine == PT_ENGINE_AUTO && _autoPhase != Decided) _error = _AutoRecord(ms);
 		_inFlightSamples = 0;
 	}
 
@@ -185,7 +209,8 @@ public:
 		_width = pixelWidth;
 		_height = pixelHeight;
 		_camera.Resize(pixelWidth, pixelHeight);
-		_opt.pixel_first = 0; _opt.pixel_count = 0;     // a tile of the old image means nothing now
+		_opt.pixel_first = 0; _opt.pixel_count = 0;     // a tile of the old image means nothing now (a TILE split derives its own)
+		_autoPhase = ProbeFused;
 		if ((_error = _AllocateDrawingMemory())) return;
 		_error = _InitializeRendering();
 	}
@@ -211,24 +236,43 @@ public:
 
 	int SetOptions(const pt_options& in) {
 		if (_error) return _error;
-		if (in.engine != PT_ENGINE_WAVEFRONT && in.engine != PT_ENGINE_FUSED) return plugin_fail(PT_ERR_INVALID, "unknown engine");
+		if (in.engine != PT_ENGINE_WAVEFRONT && in.engine != PT_ENGINE_FUSED && in.engine != PT_ENGINE_AUTO) return plugin_fail(PT_ERR_INVALID, "unknown engine");
 		if (in.rng_mode != PT_RNG_SEQUENTIAL && in.rng_mode != PT_RNG_STRIDED) return plugin_fail(PT_ERR_INVALID, "unknown rng_mode");
 		if (in.depth < 1 || in.depth > PT_MAX_DEPTH) return plugin_fail(PT_ERR_INVALID, "depth must be 1..32");
 		if (in.rng_mode == PT_RNG_STRIDED && in.stride == 0) return plugin_fail(PT_ERR_INVALID, "stride must be positive");
 		if (in.samples_per_begin == 0) return plugin_fail(PT_ERR_INVALID, "samples_per_begin must be positive");
 		if (in.shading != PT_SHADING_REFERENCE && in.shading != PT_SHADING_EXTENDED) return plugin_fail(PT_ERR_INVALID, "unknown shading");
+		if (in.split_mode != PT_SPLIT_NONE && in.split_mode != PT_SPLIT_TILE && in.split_mode != PT_SPLIT_SAMPLE) return plugin_fail(PT_ERR_INVALID, "unknown split_mode");
 		uint64_t n = (uint64_t)_width * _height;
-		uint64_t cnt = in.pixel_count ? in.pixel_count : n - std::min<uint64_t>(in.pixel_first, n);
-		if ((uint64_t)in.pixel_first + cnt > n || cnt == 0) return plugin_fail(PT_ERR_INVALID, "pixel range exceeds the image");
-		if (in.device != _opt.device && in.device >= 0) return plugin_fail(PT_ERR_STATE, "device is chosen before Create (pt_set_default_device)");
+		uint32_t ranks = in.split_mode == PT_SPLIT_NONE ? 1u : std::max(in.split_ranks, 1u);
+		if (in.split_mode != PT_SPLIT_NONE && in.split_rank >= ranks) return plugin_fail(PT_ERR_INVALID, "split_rank must be below split_ranks");
+		if (in.split_mode == PT_SPLIT_TILE) {
+			if (ranks > n) return plugin_fail(PT_ERR_INVALID, "tile split: more ranks than pixels");
+		} else {
+			uint64_t cnt = in.pixel_count ? in.pixel_count : n - std::min<uint64_t>(in.pixel_first, n);
+			if ((uint64_t)in.pixel_first + cnt > n || cnt == 0) return plugin_fail(PT_ERR_INVALID, "pixel range exceeds the image");
+		}
+		if (in.split_mode == PT_SPLIT_SAMPLE) {
+			uint32_t v = in.virtual_shards ? in.virtual_shards : PT_VIRTUAL_SHARDS;
+			if (in.rng_mode != PT_RNG_STRIDED) return plugin_fail(PT_ERR_INVALID, "sample split needs PT_RNG_STRIDED: a sample's stream must not depend on which GPU renders it");
+			if (v > 16 || (v & (v - 1))) return plugin_fail(PT_ERR_INVALID, "virtual_shards must be a power of two <= 16");
+			if (v % ranks) return plugin_fail(PT_ERR_INVALID, "split_ranks must divide virtual_shards");
+		}
+		if (in.device != _opt.device && in.device >= 0) return plugin_fail(PT_ERR_STATE, "device is chosen before Create (pt_set_default_device / pt_create_on_device)");
 		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		bool realloc = in.pixel_first != _opt.pixel_first || in.pixel_count != _opt.pixel_count ||
-		               in.samples_per_pass != _opt.samples_per_pass || in.engine != _opt.engine || in.rng_mode != _opt.rng_mode;
+		               in.samples_per_pass != _opt.samples_per_pass || in.engine != _opt.engine || in.rng_mode != _opt.rng_mode ||
+		               in.split_mode != _opt.split_mode || in.split_rank != _opt.split_rank || in.split_ranks != _opt.split_ranks ||
+		               in.virtual_shards != _opt.virtual_shards;
 		int dev = _opt.device;
 		_opt = in;
 		_opt.device = dev;
 		if (_opt.samples_per_pass == 0) _opt.samples_per_pass = 1;
+		if (_opt.split_mode == PT_SPLIT_NONE) { _opt.split_rank = 0; _opt.split_ranks = 1; }
+		if (_opt.split_ranks == 0) _opt.split_ranks = 1;
+		if (_opt.virtual_shards == 0) _opt.virtual_shards = PT_VIRTUAL_SHARDS;
+		_autoPhase = ProbeFused;
 		if (realloc) { if ((_error = _AllocateDrawingMemory())) return _error; }
 		return _error = _InitializeRendering();
 	}
@@ -250,7 +294,20 @@ public:
 		PT_TRY(pt_hip_stream_synchronize(_stream));
 		pt_hip_free(_dev.scene);
 		_dev.scene = fresh; _nTris = nt; _nMats = nm; _sceneHasBvh = has_bvh != 0;
+		_autoPhase = ProbeFused;
 		return _error = _InitializeRendering();
+	}
+
+	bool SampleSplit() const { return _opt.split_mode == PT_SPLIT_SAMPLE; }
+
+	// SAMPLE split: makes _dev.image the combine of the shard means.  A single instance owns every shard and combines by
+	// itself; with more ranks the image comes from pt_combine_instances / pt_dist_combine.
+	int _EnsureImage(const char* who) {
+		if (_imageCurrent) return PT_OK;
+		if (_ranks > 1) return plugin_fail(PT_ERR_STATE, std::string(who) + ": the shards of a multi-instance sample split are combined by pt_combine_instances or pt_dist_combine first");
+		PT_TRY(pt_hip_comm_exchange_combine(nullptr, 0, 1, _dev.mean, _localShards, _pitch, _dev.mean, _dev.image, _stream));
+		_imageCurrent = true;
+		return PT_OK;
 	}
 
 	int Readback(float* rgba, size_t n_floats) {
@@ -259,7 +316,8 @@ public:
 		if (!rgba) return plugin_fail(PT_ERR_INVALID, "readback: null pointer");
 		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "readback: n_floats must be 4 * pixel_count");
 		if (_drawState == Drawing) FinalizeDrawing();
-		PT_TRY(pt_hip_memcpy_d2h(rgba, _dev.mean, n_floats * sizeof(float), _stream));
+		if (SampleSplit()) { if (int rc = _EnsureImage("readback")) return rc; }
+		PT_TRY(pt_hip_memcpy_d2h(rgba, SampleSplit() ? _dev.image : _dev.mean, n_floats * sizeof(float), _stream));
 		return PT_OK;
 	}
 	int ReadbackRng(uint32_t* states, size_t n) {
@@ -271,13 +329,22 @@ public:
 		PT_TRY(pt_hip_memcpy_d2h(states, _dev.rng, n * sizeof(uint32_t), _stream));
 		return PT_OK;
 	}
+	// n_floats = 4 * pixel_count: the image (SAMPLE split: the combined one); 4 * pitch * local shards: the raw shard means
+	int _CopySource(const char* who, size_t n_floats, const void** src) {
+		if (SampleSplit() && n_floats == (size_t)_pitch * _localShards * 4 && !(_localShards == 1 && _ranks == 1 && _pitch == _pixelCount)) { *src = _dev.mean; return PT_OK; }
+		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, std::string(who) + ": n_floats must be 4 * pixel_count (or, sample split, 4 * pitch * local shards)");
+		if (SampleSplit()) { if (int rc = _EnsureImage(who)) return rc; *src = _dev.image; }
+		else *src = _dev.mean;
+		return PT_OK;
+	}
 	int CopyMean(void* device_dst, size_t n_floats) {
 		if (_error) return _error;
 		DeviceScope bind(_device);
 		if (!device_dst) return plugin_fail(PT_ERR_INVALID, "copy_mean: null pointer");
-		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "copy_mean: n_floats must be 4 * pixel_count");
 		if (_drawState == Drawing) FinalizeDrawing();
-		PT_TRY(pt_hip_memcpy_d2d(device_dst, _dev.mean, n_floats * sizeof(float), _stream));
+		const void* src = nullptr;
+		if (int rc = _CopySource("copy_mean", n_floats, &src)) return rc;
+		PT_TRY(pt_hip_memcpy_d2d(device_dst, src, n_floats * sizeof(float), _stream));
 		PT_TRY(pt_hip_stream_synchronize(_stream));
 		return PT_OK;
 	}
@@ -285,13 +352,19 @@ public:
 		if (_error) return _error;
 		DeviceScope bind(_device);
 		if (!device_dst) return plugin_fail(PT_ERR_INVALID, "copy_mean_async: null pointer");
-		if (n_floats != (size_t)_pixelCount * 4) return plugin_fail(PT_ERR_INVALID, "copy_mean_async: n_floats must be 4 * pixel_count");
-		PT_TRY(pt_hip_memcpy_d2d(device_dst, _dev.mean, n_floats * sizeof(float), _stream));
+		const void* src = nullptr;
+		if (int rc = _CopySource("copy_mean_async", n_floats, &src)) return rc;
+		PT_TRY(pt_hip_memcpy_d2d(device_dst, src, n_floats * sizeof(float), _stream));
 		return PT_OK;
 	}
 	void* Stream() const { return _stream; }
 	void* DeviceMean() { if (_drawState == Drawing) FinalizeDrawing(); return _dev.mean; }
 	int Device() const { return _device; }
+	void ShardLayout(uint32_t* local, uint32_t* pitch, uint32_t* v) const {
+		if (local) *local = _localShards;
+		if (pitch) *pitch = _pitch;
+		if (v) *v = _vShards;
+	}
 
 	int Stats(pt_stats* out) {
 		if (_error) return _error;
@@ -304,6 +377,8 @@ public:
 		out->frames = _frameNumber;
 		for (int b = 0; b < PT_MAX_DEPTH; b++) out->rays_per_bounce[b] = words[4 + b];
 		out->last_render_ms = _lastMs; out->total_render_ms = _totalMs; out->renders = _renders;
+		out->engine_in_use = _opt.engine != PT_ENGINE_AUTO ? _opt.engine : _autoPhase == Decided ? _autoChoice : (uint32_t)PT_ENGINE_AUTO;
+		out->auto_rays_per_ms[0] = _autoRate[0]; out->auto_rays_per_ms[1] = _autoRate[1];
 		return PT_OK;
 	}
 	void Size(int* w, int* h, uint32_t* first, uint32_t* count) const {
@@ -313,7 +388,69 @@ public:
 		if (count) *count = _pixelCount;
 	}
 
+	// ---- sample split: the one exchange ----
+	// pt_combine_instances: all instances of a split live in this process.  `this` is the root: it gathers every shard
+	// mean onto its own GPU (peer copies on its stream, over xGMI between GPUs) and runs the tree there.
+	int CombineInstances(PathTracer* const* all, uint32_t n) {
+		if (_error) return _error;
+		if (!SampleSplit()) return plugin_fail(PT_ERR_STATE, "combine_instances: the instances are not in PT_SPLIT_SAMPLE mode");
+		if (n != _ranks) return plugin_fail(PT_ERR_INVALID, "combine_instances: pass all split_ranks instances of the split");
+		std::vector<PathTracer*> by_rank(n, nullptr);
+		for (uint32_t k = 0; k < n; k++) {
+			PathTracer* t = all[k];
+			if (!t) return plugin_fail(PT_ERR_INVALID, "combine_instances: null handle");
+			if (t->_error) return t->_error;
+			if (!t->SampleSplit() || t->_ranks != _ranks || t->_vShards != _vShards || t->_pixelCount != _pixelCount || t->_pixelFirst != _pixelFirst ||
+			    t->_width != _width || t->_height != _height || t->_frameNumber != _frameNumber || t->_opt.split_rank >= n || by_rank[t->_opt.split_rank])
+				return plugin_fail(PT_ERR_INVALID, "combine_instances: the handles are not the ranks 0..n-1 of one split at the same sample count");
+			by_rank[t->_opt.split_rank] = t;
+		}
+		for (PathTracer* t : by_rank) { DeviceScope bind(t->_device); if (t->_drawState == Drawing) t->FinalizeDrawing(); if (t->_error) return t->_error; }
+		DeviceScope bind(_device);
+		size_t row = (size_t)_pitch * 16;
+		if (int rc = _EnsureStacked((size_t)_vShards * row)) return rc;
+		for (PathTracer* t : by_rank)
+			for (uint32_t j = 0; j < t->_localShards; j++) {
+				uint32_t v = t->_opt.split_rank + j * _ranks;
+				PT_TRY(pt_hip_memcpy_peer((char*)_dev.stacked + (size_t)v * row, _device, (const char*)t->_dev.mean + (size_t)j * row, t->_device, row, _stream));
+			}
+		PT_TRY(pt_hip_comm_exchange_combine(nullptr, 0, 1, _dev.stacked, _vShards, _pitch, _dev.stacked, _dev.image, _stream));
+		PT_TRY(pt_hip_stream_synchronize(_stream));
+		_imageCurrent = true;
+		return PT_OK;
+	}
+
+	int DistInit(const void* id128) {
+		if (_error) return _error;
+		if (!SampleSplit()) return plugin_fail(PT_ERR_STATE, "dist_init: set PT_SPLIT_SAMPLE options first");
+		DeviceScope bind(_device);
+		if (_comm) { PT_TRY(pt_hip_comm_destroy(_comm)); _comm = nullptr; }
+		PT_TRY(pt_hip_comm_create(&_comm, id128, (int)_opt.split_rank, (int)_ranks));
+		return PT_OK;
+	}
+	int DistCombine() {
+		if (_error) return _error;
+		if (!SampleSplit()) return plugin_fail(PT_ERR_STATE, "dist_combine: the instance is not in PT_SPLIT_SAMPLE mode");
+		if (_ranks > 1 && !_comm) return plugin_fail(PT_ERR_STATE, "dist_combine: pt_dist_init first");
+		DeviceScope bind(_device);
+		if (_drawState == Drawing) FinalizeDrawing();
+		if (_error) return _error;
+		if (int rc = _EnsureStacked((size_t)_vShards * _slice * 16)) return rc;
+		PT_TRY(pt_hip_comm_exchange_combine(_comm, (int)_opt.split_rank, (int)_ranks, _dev.mean, _localShards, _slice, _dev.stacked, _dev.image, _stream));
+		PT_TRY(pt_hip_stream_synchronize(_stream));
+		_imageCurrent = true;
+		return PT_OK;
+	}
+
 private:
+	int _EnsureStacked(size_t bytes) {
+		if (_stackedBytes >= bytes) return PT_OK;
+		pt_hip_free(_dev.stacked); _dev.stacked = nullptr; _stackedBytes = 0;
+		PT_TRY(pt_hip_malloc(&_dev.stacked, bytes));
+		_stackedBytes = bytes;
+		return PT_OK;
+	}
+
 	pt_frame _Frame() const {
 		pt_frame f{};
 		f.width = _width; f.height = _height;
@@ -328,28 +465,54 @@ private:
 		return f;
 	}
 
+	bool _NeedsWorkspace() const { return _opt.engine == PT_ENGINE_WAVEFRONT || _opt.engine == PT_ENGINE_AUTO; }
+	int _EnsureWorkspace() {
+		if (_dev.workspace) return PT_OK;
+		uint32_t spp = _opt.rng_mode == PT_RNG_STRIDED ? _opt.samples_per_pass : 1;
+		_workspaceBytes = pt_hip_wavefront_workspace_bytes(_pixelCount, spp, _opt.depth);
+		PT_TRY(pt_hip_malloc(&_dev.workspace, _workspaceBytes));
+		return PT_OK;
+	}
+
 	// PathTracer.cu:217-233
 	int _AllocateDrawingMemory() {
 		uint64_t n = (uint64_t)_width * _height;
 		if (n > 0x7FFFFFFFull) return plugin_fail(PT_ERR_LIMIT, "image larger than 2^31-1 pixels");
-		_pixelFirst = _opt.pixel_first;
-		_pixelCount = _opt.pixel_count ? _opt.pixel_count : (uint32_t)(n - _pixelFirst);
-		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace);
-		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _workspaceBytes = 0;
+		_ranks = _opt.split_mode == PT_SPLIT_NONE ? 1u : std::max(_opt.split_ranks, 1u);
+		if (_opt.split_mode == PT_SPLIT_TILE) {
+			if (_ranks > n || _opt.split_rank >= _ranks) return plugin_fail(PT_ERR_INVALID, "tile split does not fit the image");
+			_pixelFirst = (uint32_t)(n * _opt.split_rank / _ranks);
+			_pixelCount = (uint32_t)(n * (_opt.split_rank + 1) / _ranks) - _pixelFirst;
+		} else {
+			if (_opt.pixel_first >= n || (uint64_t)_opt.pixel_first + _opt.pixel_count > n) { _opt.pixel_first = 0; _opt.pixel_count = 0; }
+			_pixelFirst = _opt.pixel_first;
+			_pixelCount = _opt.pixel_count ? _opt.pixel_count : (uint32_t)(n - _pixelFirst);
+		}
+		if (SampleSplit()) {
+			_vShards = _opt.virtual_shards ? _opt.virtual_shards : PT_VIRTUAL_SHARDS;
+			_localShards = _vShards / _ranks;
+			_slice = (_pixelCount + _ranks - 1) / _ranks;
+			_pitch = _slice * _ranks;
+		} else {
+			_vShards = 1; _localShards = 1; _slice = _pixelCount; _pitch = _pixelCount;
+		}
+		_imageCurrent = false;
+		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked);
+		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _dev.image = nullptr; _dev.stacked = nullptr;
+		_workspaceBytes = 0; _stackedBytes = 0;
 		// the short division of the ray set-up is used only for sizes it is verified for (exhaustively, on the device)
 		int okW = 0, okH = 0;
 		PT_TRY(pt_hip_verify_fast_div((uint32_t)_width, &okW, _stream));
 		PT_TRY(pt_hip_verify_fast_div((uint32_t)_height, &okH, _stream));
 		_frameFlags = (okW && okH) ? PT_FRAME_FAST_DIV : 0u;
 		PT_TRY(pt_hip_malloc((void**)&_dev.rng, (size_t)_pixelCount * sizeof(uint32_t)));
-		PT_TRY(pt_hip_malloc(&_dev.mean, (size_t)_pixelCount * 4 * sizeof(float)));
+		size_t mean_floats = (size_t)_pitch * _localShards * 4;
+		PT_TRY(pt_hip_malloc(&_dev.mean, mean_floats * sizeof(float)));
+		if (SampleSplit()) PT_TRY(pt_hip_malloc(&_dev.image, (size_t)_pitch * 4 * sizeof(float)));
 		// the reference's surface starts white (Surface.cpp:99-115); frame 0 multiplies it by 0
-		PT_TRY(pt_hip_fill_f32((float*)_dev.mean, 1.0f, (size_t)_pixelCount * 4, _stream));
-		if (_opt.engine == PT_ENGINE_WAVEFRONT) {
-			uint32_t spp = _opt.rng_mode == PT_RNG_STRIDED ? _opt.samples_per_pass : 1;
-			_workspaceBytes = pt_hip_wavefront_workspace_bytes(_pixelCount, spp, _opt.depth);
-			PT_TRY(pt_hip_malloc(&_dev.workspace, _workspaceBytes));
-		}
+		PT_TRY(pt_hip_fill_f32((float*)_dev.mean, 1.0f, mean_floats, _stream));
+		if (SampleSplit()) PT_TRY(pt_hip_fill_f32((float*)_dev.image, 1.0f, (size_t)_pitch * 4, _stream));
+		if (_opt.engine == PT_ENGINE_WAVEFRONT) { if (int rc = _EnsureWorkspace()) return rc; }     // AUTO: when its probe comes
 		return PT_OK;
 	}
 
@@ -358,25 +521,66 @@ private:
 		_shouldRestartRendering = false;
 		_frameNumber = 0;
 		_totalMs = 0.0; _renders = 0;
+		_imageCurrent = false;
 		pt_frame f = _Frame();
 		PT_TRY(pt_hip_rng_seed(&f, _dev.rng, _stream));
 		PT_TRY(pt_hip_memset(_dev.stats, 0, PT_STATS_WORDS * sizeof(uint64_t), _stream));
 		return PT_OK;
 	}
 
-	// PathTracer.cu:116-157, for `samples` samples
+	int _ReadRays(uint64_t* rays) {
+		PT_TRY(pt_hip_memcpy_d2h(rays, _dev.stats, sizeof(uint64_t), _stream));
+		return PT_OK;
+	}
+
+	// FinalizeDrawing of a probe render: device time and rays of the engine that just ran
+	int _AutoRecord(float ms) {
+		uint64_t rays = 0;
+		if (int rc = _ReadRays(&rays)) return rc;
+		double rate = ms > 0.0f ? (double)(rays - _raysBefore) / ms : 0.0;
+		_autoRate[_engineInFlight] = rate;
+		if (_autoPhase == ProbeFused) _autoPhase = ProbeWavefront;
+		else {
+			_autoChoice = _autoRate[PT_ENGINE_WAVEFRONT] > _autoRate[PT_ENGINE_FUSED] ? PT_ENGINE_WAVEFRONT : PT_ENGINE_FUSED;
+			_autoPhase = Decided;
+			if (_autoChoice == PT_ENGINE_FUSED) { pt_hip_free(_dev.workspace); _dev.workspace = nullptr; _workspaceBytes = 0; }
+		}
+		return PT_OK;
+	}
+
+	uint32_t _PickEngine() {
+		if (_opt.engine != PT_ENGINE_AUTO) return _opt.engine;
+		if (_autoPhase == Decided) return _autoChoice;
+		uint32_t e = _autoPhase == ProbeFused ? PT_ENGINE_FUSED : PT_ENGINE_WAVEFRONT;
+		// the wavefront probe needs its queues; if they cannot be had the fused engine stays
+		if (e == PT_ENGINE_WAVEFRONT && _EnsureWorkspace() != PT_OK) { _autoChoice = PT_ENGINE_FUSED; _autoPhase = Decided; return PT_ENGINE_FUSED; }
+		return e;
+	}
+
+	// PathTracer.cu:116-157, for `samples` samples (SAMPLE split: for each of this instance's shards)
 	int _Enqueue(uint32_t samples) {
 		if (samples == 0) return PT_OK;
 		if ((uint64_t)_frameNumber + samples > 0xFFFFFFFFull) return plugin_fail(PT_ERR_LIMIT, "frame counter would overflow");
+		if (SampleSplit() && (uint64_t)_frameNumber + samples > PT_SHARD_SPAN) return plugin_fail(PT_ERR_LIMIT, "sample split: more than PT_SHARD_SPAN samples per shard");
 		pt_frame f = _Frame();
-		uint32_t frame_first = _opt.sample_offset + _frameNumber;
+		uint32_t engine = _PickEngine();
+		if (_opt.engine == PT_ENGINE_AUTO && _autoPhase != Decided) {
+			if (int rc = _ReadRays(&_raysBefore)) return rc;          // (waits for what is on the stream: probes only)
+		}
+		_engineInFlight = engine;
+		_imageCurrent = false;
 		PT_TRY(pt_hip_event_record(_evStart, _stream));
-		if (_opt.engine == PT_ENGINE_WAVEFRONT) {
-			PT_TRY(pt_hip_render_wavefront(&f, _dev.scene, _nTris, _nMats, frame_first, _frameNumber, samples, _opt.samples_per_pass,
-			                               _dev.rng, _dev.mean, _dev.workspace, _workspaceBytes, _dev.stats, _stream));
-		} else {
-			PT_TRY(pt_hip_render_fused(&f, _dev.scene, _nTris, _nMats, frame_first, _frameNumber, samples,
-			                           _dev.rng, _dev.mean, _dev.stats, _stream));
+		for (uint32_t j = 0; j < _localShards; j++) {
+			uint32_t shard = SampleSplit() ? _opt.split_rank + j * _ranks : 0u;
+			uint32_t frame_first = _opt.sample_offset + shard * PT_SHARD_SPAN + _frameNumber;
+			void* mean = (char*)_dev.mean + (size_t)j * _pitch * 16;
+			if (engine == PT_ENGINE_WAVEFRONT) {
+				PT_TRY(pt_hip_render_wavefront(&f, _dev.scene, _nTris, _nMats, frame_first, _frameNumber, samples, _opt.samples_per_pass,
+				                               _dev.rng, mean, _dev.workspace, _workspaceBytes, _dev.stats, _stream));
+			} else {
+				PT_TRY(pt_hip_render_fused(&f, _dev.scene, _nTris, _nMats, frame_first, _frameNumber, samples,
+				                           _dev.rng, mean, _dev.stats, _stream));
+			}
 		}
 		PT_TRY(pt_hip_event_record(_evStop, _stream));
 		_inFlightSamples = samples;
@@ -492,5 +696,42 @@ int pt_get_stats(pt_handle* h, pt_stats* out) {
 	return tracer->Stats(out);
 }
 int pt_get_size(pt_handle* h, int* w, int* hgt, uint32_t* first, uint32_t* count) { PT_HANDLE(h); tracer->Size(w, hgt, first, count); return PT_OK; }
+
+int pt_combine_instances(pt_handle* const* handles, uint32_t n) {
+	if (!handles || n == 0 || !handles[0]) return plugin_fail(PT_ERR_INVALID, "combine_instances: no handles");
+	std::vector<PathTracer*> all(n);
+	for (uint32_t k = 0; k < n; k++) all[k] = handles[k] ? as_tracer(handles[k]) : nullptr;
+	return all[0]->CombineInstances(all.data(), n);
+}
+int pt_dist_unique_id(void* id128) {
+	if (int rc = pt_hip_comm_unique_id(id128)) return hip_layer_fail(rc, "pt_hip_comm_unique_id");
+	return PT_OK;
+}
+int pt_dist_init(pt_handle* h, const void* id128) {
+	PT_HANDLE(h);
+	if (!id128) return plugin_fail(PT_ERR_INVALID, "dist_init: null id");
+	return tracer->DistInit(id128);
+}
+int pt_dist_combine(pt_handle* h) { PT_HANDLE(h); return tracer->DistCombine(); }
+int pt_get_shard_layout(pt_handle* h, uint32_t* local_shards, uint32_t* pitch_pixels, uint32_t* virtual_shards) {
+	PT_HANDLE(h);
+	tracer->ShardLayout(local_shards, pitch_pixels, virtual_shards);
+	return PT_OK;
+}
+pt_handle* pt_create_on_device(int device, int w, int hgt, const pt_camera_data* camera) {
+	if (w <= 0 || hgt <= 0 || !camera) { plugin_fail(PT_ERR_INVALID, "create_on_device: width/height must be positive and camera non-null"); return nullptr; }
+	CameraData c;
+	std::memcpy(static_cast<void*>(&c), camera, sizeof(c));
+	PathTracer* tracer = new PathTracer(w, hgt, &c);
+	if (device >= 0) tracer->SetDevice(device);
+	if (tracer->Initialize() != PT_OK) {
+		std::string msg = t_plugin_error;
+		std::cout << "Failed to create HIP path tracer: " << msg << std::endl;
+		delete tracer;
+		t_plugin_error = msg;
+		return nullptr;
+	}
+	return static_cast<IPathTracer*>(tracer);
+}
 
 } // extern "C"

@@ -1,59 +1,58 @@
-"""Sample split of one frame over the GPUs of a node (partitioning A).
+"""Sample split of one frame over the GPUs of a node (partitioning A) -- the torch.distributed form of
+the exchange (one process per GPU; backend "nccl" is RCCL on ROCm).  The C++ form is pt_dist_combine /
+pt_combine_instances (include/pt_plugin.h); both follow the same layout and give the same bits.
 
-Not in the reference (single GPU, PathTracer.cu:25).  Rank r renders its own block of samples of
-the SAME frame into its own running mean (strided RNG, so sample n of pixel i is the same stream
-whichever GPU renders it); the one exchange step then combines the ranks' means in a FIXED
-pairwise order, ((m0+m1)+(m2+m3))+... times 1/world, so the image does not depend on arrival
-order.  Traffic per rank: one image out as `world` slices (all_to_all over xGMI, every link used
-at once), the tree on its own slice, one all_gather of the combined slices.
+Not in the reference (single GPU, PathTracer.cu:25).  The frame's samples are dealt to V = 8 VIRTUAL shards whatever
+the GPU count (include/pt_plugin.h, PT_SPLIT_SAMPLE): shard v takes the RNG sample indices v * PT_SHARD_SPAN + k and
+keeps a running mean of its own, rank g of G renders the shards {v : v % G == g}.  The image is the fixed-order
+pairwise tree ((m0+m1)+(m2+m3))+((m4+m5)+(m6+m7)) times 1/8 over the shard means: the same bits on 1, 2, 4 or 8 GPUs
+and for any arrival order.
 
-`torch.distributed` is plumbing here: backend "nccl" is RCCL on ROCm; "gloo" (CPU tests) has no
-all_to_all, so the same routine falls back to all_gather there.
+The one exchange: for each of its V/G local shards a rank sends slice r of that shard's mean to rank r
+(all_to_all_single: every xGMI link busy at once) and receives its own slice of the shards the others hold -- they land
+shard-major in virtual-shard order --, runs the tree on its slice, and one all_gather puts the image on every rank.
+`torch.distributed` is plumbing here; gloo (CPU tests) runs the very same calls.
 """
 from __future__ import annotations
 
 from typing import Callable
 
-
-def shard_samples(samples_per_rank: int, rank: int) -> int:
-    """RNG sample index of rank `rank`'s first sample (pt_options.sample_offset)."""
-    return rank * samples_per_rank
+VIRTUAL_SHARDS = 8            # PT_VIRTUAL_SHARDS
+SHARD_SPAN = 1 << 20          # PT_SHARD_SPAN
 
 
-def exchange_and_combine(mean, dist, combine_slices: Callable, out=None, scratch=None, slice_out=None):
-    """mean: flat float32 tensor (4 * n_pixels) holding this rank's running mean.
+def local_shards(rank: int, world: int, virtual_shards: int = VIRTUAL_SHARDS):
+    """Virtual shards rendered by `rank`, in the order the plugin keeps their means."""
+    if world < 1 or virtual_shards % world:
+        raise ValueError(f"{world} ranks do not divide {virtual_shards} virtual shards")
+    return [rank + j * world for j in range(virtual_shards // world)]
 
-    combine_slices(stacked, shards, n_pixels_in_slice, out_slice): fixed-order tree over
-    `shards` shard-major slices (pt_hip_combine_shards on the GPU).
-    Returns the combined frame (every rank gets all of it)."""
-    import torch
 
-    world = dist.get_world_size()
-    rank = dist.get_rank()
-    n = mean.numel()
-    if n % (4 * world) != 0:
-        raise ValueError(f"image of {n // 4} pixels does not split evenly over {world} ranks")
-    slice_floats = n // world
-    stacked = scratch if scratch is not None else torch.empty(world * slice_floats, dtype=mean.dtype, device=mean.device)
-    if dist.get_backend() == "gloo":
-        gathered = [torch.empty_like(mean) for _ in range(world)]
-        dist.all_gather(gathered, mean)
-        for r in range(world):
-            stacked[r * slice_floats:(r + 1) * slice_floats] = gathered[r][rank * slice_floats:(rank + 1) * slice_floats]
-    else:
-        dist.all_to_all_single(stacked, mean)               # slice j of every rank's mean -> rank j, shard-major
-    my_slice = slice_out if slice_out is not None else torch.empty(slice_floats, dtype=mean.dtype, device=mean.device)
-    combine_slices(stacked, world, slice_floats // 4, my_slice)
-    image = out if out is not None else torch.empty(n, dtype=mean.dtype, device=mean.device)
-    dist.all_gather_into_tensor(image, my_slice) if dist.get_backend() != "gloo" else _gloo_all_gather(dist, image, my_slice, world)
+def slice_pixels(pixel_count: int, world: int) -> int:
+    """Pixels per exchanged slice: the image is padded to world * slice pixels (the plugin's pitch)."""
+    return (pixel_count + world - 1) // world
+
+
+def exchange_and_combine(shard_means, dist, combine_slices: Callable, stacked, image, group=None):
+    """shard_means: flat float32 tensor, [V/G local shards][pitch * 4] with pitch = world * slice pixels
+    (pt_copy_mean of a PT_SPLIT_SAMPLE instance).  stacked: scratch, V * slice * 4 floats.  image: pitch * 4 floats,
+    the result, on every rank.  combine_slices(stacked, shards, n_pixels_in_slice, out_slice): the fixed-order tree over
+    `shards` shard-major slices (pt_hip_combine_shards on the GPU)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    pitch_floats = image.numel()
+    if pitch_floats % (4 * world) or shard_means.numel() % pitch_floats:
+        raise ValueError("image must be world * slice pixels, shard_means a whole number of images")
+    n_local = shard_means.numel() // pitch_floats
+    slice_floats = pitch_floats // world
+    if stacked.numel() < n_local * world * slice_floats:
+        raise ValueError("stacked too small")
+    for j in range(n_local):
+        # slice r of local shard j (virtual shard rank + j*world) -> rank r; from rank r comes my slice of ITS shard
+        # r + j*world, which is position j*world + r of `stacked`: shard-major in virtual-shard order
+        dist.all_to_all_single(stacked[j * world * slice_floats:(j + 1) * world * slice_floats],
+                               shard_means[j * pitch_floats:(j + 1) * pitch_floats], group=group)
+    mine = image[rank * slice_floats:(rank + 1) * slice_floats]
+    combine_slices(stacked, n_local * world, slice_floats // 4, mine)
+    dist.all_gather_into_tensor(image, mine, group=group)
     return image
-
-
-def _gloo_all_gather(dist, image, my_slice, world):
-    import torch
-
-    parts = [torch.empty_like(my_slice) for _ in range(world)]
-    dist.all_gather(parts, my_slice)
-    k = my_slice.numel()
-    for r in range(world):
-        image[r * k:(r + 1) * k] = parts[r]

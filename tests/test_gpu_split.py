@@ -1,0 +1,185 @@
+"""Multi-GPU splits behind the plugin boundary (include/pt_plugin.h; no reference counterpart: single device,
+PathTracer.cu:25) and PT_ENGINE_AUTO, on one GPU: the instances of a split share device 0 here, the code path is the one
+G GPUs run (per-instance device binding, peer copies, the RCCL exchange with a communicator of one rank).
+
+Bar: bit for bit.  Sample split: the image over 8 virtual shards is the oracle's pto_render_sharded_span and does not
+depend on the number of instances.  Tile split: the tiles side by side are the single-instance sequential image."""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENGINES = [("fused", 1), ("wavefront", 0)]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(img, ref, what):
+    diff = (bits(img) != bits(ref)).any(axis=1)
+    assert not diff.any(), f"{what}: {int(diff.sum())} of {len(diff)} pixels differ; first at {int(np.argmax(diff))}: {img[np.argmax(diff)]} vs {ref[np.argmax(diff)]}"
+
+
+def _sharded_reference(oracle, w, h, per_shard, depth=10, stride=35, scene=None):
+    p = oracle.params(w, h, depth=depth, rng_mode=oracle.RNG_STRIDED, stride=stride, spp=per_shard * 8)
+    return oracle.render_sharded(p, 8, scene=scene, span=1 << 20)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_sample_split_single_instance(pt, oracle, name, engine):
+    """one instance renders all 8 virtual shards and combines them itself on readback"""
+    w, h, per = 65, 33, 3
+    want, st_ref = _sharded_reference(oracle, w, h, per)
+    with pt.PathTracer(w, h) as tr:
+        tr.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, split_mode=pt.PT_SPLIT_SAMPLE, samples_per_pass=2)
+        assert tr.shard_layout() == (8, w * h, 8)
+        tr.render(2)
+        tr.render(1)
+        img, st = tr.readback(), tr.stats()
+    assert_bit_equal(img, want, name)
+    assert st.frames == per and st.rays == st_ref.rays and st.paths == w * h * per * 8
+
+
+@pytest.mark.parametrize("instances", [1, 2, 4, 8])
+def test_sample_split_image_does_not_depend_on_the_instance_count(pt, oracle, instances):
+    """G instances (threads, one each) render their shares of the 8 virtual shards, pt_combine_instances puts the image in
+    instance 0: the oracle's sharded mean for every G, on a scene whose paths bounce (all materials, depth 12)"""
+    V, T, M = scenes.all_materials_scene()
+    w, h, per, depth = 97, 41, 4, 12
+    stride = 2 + 33 * depth
+    want, st_ref = _sharded_reference(oracle, w, h, per, depth=depth, stride=stride, scene=oracle.make_scene(V, T, M))
+    tracers = [pt.PathTracer(w, h, device=0) for _ in range(instances)]
+    try:
+        for g, tr in enumerate(tracers):
+            tr.set_scene(*pt.make_scene(V, T, M))
+            tr.set_options(engine=g % 2, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=3,
+                           split_mode=pt.PT_SPLIT_SAMPLE, split_rank=g, split_ranks=instances)
+            assert tr.shard_layout()[0] == 8 // instances
+        errors = []
+
+        def drive(tr):
+            try:
+                tr.render(per - 1)
+                tr.BeginDrawing()
+                tr.FinalizeDrawing()
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=drive, args=(tr,)) for tr in tracers]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert not errors, errors
+        if instances > 1:
+            with pytest.raises(pt.PathTracerError):
+                tracers[0].readback()                       # no combine yet
+        pt.combine_instances(tracers[::-1])                 # any order; the image lands in the first handle passed
+        img = tracers[-1].readback()
+        rays = sum(tr.stats().rays for tr in tracers)
+    finally:
+        for tr in tracers:
+            tr.Destroy()
+    assert_bit_equal(img, want, f"{instances} instances")
+    assert rays == st_ref.rays
+
+
+def test_dist_combine_with_a_communicator_of_one_rank(pt, oracle):
+    """pt_dist_*: librccl is loaded, a communicator made from a unique id, and the exchange (grouped ncclSend/ncclRecv of
+    the slices, tree, ncclAllGather) runs through RCCL -- with one rank, which is all one GPU allows"""
+    w, h, per = 64, 36, 2
+    want, _ = _sharded_reference(oracle, w, h, per)
+    with pt.PathTracer(w, h, device=0) as tr:
+        tr.set_options(engine=pt.PT_ENGINE_FUSED, rng_mode=pt.PT_RNG_STRIDED, stride=35, split_mode=pt.PT_SPLIT_SAMPLE, split_rank=0, split_ranks=1)
+        tr.dist_init(pt.dist_unique_id())
+        tr.render(per)
+        tr.dist_combine()
+        img = tr.readback()
+    assert_bit_equal(img, want, "dist_combine, world of one")
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+def test_tile_split_option(pt, oracle, name, engine):
+    w, h, spp, ranks = 80, 45, 3, 3
+    ref, ref_rng, _, _ = oracle.render(oracle.params(w, h, spp=spp))
+    parts, rngs, at = [], [], 0
+    for g in range(ranks):
+        with pt.PathTracer(w, h) as tr:
+            tr.set_options(engine=engine, split_mode=pt.PT_SPLIT_TILE, split_rank=g, split_ranks=ranks)
+            first, count = tr.size()[2:]
+            assert first == at
+            at += count
+            tr.render(spp)
+            parts.append(tr.readback())
+            rngs.append(tr.readback_rng())
+    assert at == w * h
+    assert_bit_equal(np.concatenate(parts), ref, name)
+    assert np.array_equal(np.concatenate(rngs), ref_rng)
+
+
+def test_split_option_errors(pt):
+    with pt.PathTracer(32, 16) as tr:
+        for bad in (dict(split_mode=pt.PT_SPLIT_SAMPLE),                                           # sequential streams
+                    dict(split_mode=pt.PT_SPLIT_SAMPLE, rng_mode=1, split_ranks=3),                 # 3 does not divide 8
+                    dict(split_mode=pt.PT_SPLIT_SAMPLE, rng_mode=1, split_ranks=2, split_rank=2),
+                    dict(split_mode=pt.PT_SPLIT_SAMPLE, rng_mode=1, virtual_shards=6),
+                    dict(split_mode=pt.PT_SPLIT_TILE, split_ranks=4, split_rank=4),
+                    dict(split_mode=7)):
+            with pytest.raises(pt.PathTracerError):
+                tr.set_options(**bad)
+        tr.render(1)                                            # the instance still works
+
+
+@pytest.mark.parametrize("instances,mode", [(2, "sample"), (4, "sample"), (3, "tile")])
+def test_cpp_multi_gpu_host(pt, oracle, tmp_path, instances, mode):
+    """tests/host/multi_gpu_host.cpp: G instances created with pt_create_on_device, one std::thread each calling through
+    the IPathTracer vtable, pt_combine_instances / tile readback -- the native multi-GPU surface, no Python in it"""
+    w, h, frames, spf = 120, 68, 2, 3
+    out = tmp_path / "multi.raw"
+    args = [os.path.join(ROOT, "tests", "host", "multi_gpu_host"), str(instances), str(w), str(h), str(frames), str(spf), str(out)]
+    if mode == "tile":
+        args.append("tile")
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.fromfile(out, dtype=np.float32).reshape(-1, 4)
+    if mode == "tile":
+        want, _, _, _ = oracle.render(oracle.params(w, h, spp=frames * spf))
+    else:
+        want, _ = _sharded_reference(oracle, w, h, frames * spf)
+    assert_bit_equal(img, want, f"C++ host, {instances} instances, {mode} split")
+    assert f"instances {instances}" in r.stdout
+
+
+@pytest.mark.parametrize("scene_name", ["default", "materials", "synthetic2500"])
+def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
+    """PT_ENGINE_AUTO (the default): first render fused, second wavefront, then the faster of the two -- the image is the
+    oracle's whichever runs, and a camera restart keeps the decision"""
+    V, T, M = {"default": scenes.default_scene, "materials": scenes.all_materials_scene, "synthetic2500": lambda: scenes.synthetic_scene(2500)}[scene_name]()
+    w, h = 200, 120
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=7), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        assert tr.get_options().engine == pt.PT_ENGINE_AUTO
+        tr.set_scene(*pt.make_scene(V, T, M))
+        assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO
+        tr.render(3)
+        tr.render(3)
+        st = tr.stats()
+        assert st.engine_in_use in (pt.PT_ENGINE_FUSED, pt.PT_ENGINE_WAVEFRONT)
+        assert st.auto_rays_per_ms[0] > 0 and st.auto_rays_per_ms[1] > 0
+        assert st.engine_in_use == (pt.PT_ENGINE_WAVEFRONT if st.auto_rays_per_ms[0] > st.auto_rays_per_ms[1] else pt.PT_ENGINE_FUSED)
+        tr.render(1)
+        img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+        assert_bit_equal(img, ref, f"auto on {scene_name}")
+        assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
+        chosen = st.engine_in_use
+        tr.Update(pt.CameraData(fieldOfView=80.0))            # camera restart: same decision, fresh accumulation
+        tr.render(2)
+        assert tr.stats().engine_in_use == chosen and tr.stats().frames == 2
+        img2 = tr.readback()
+    ref2, _, _, _ = oracle.render(oracle.params(w, h, cam=oracle.make_camera(fov=80.0), spp=2), scene=oracle.make_scene(V, T, M))
+    assert_bit_equal(img2, ref2, f"auto on {scene_name} after a camera restart")
