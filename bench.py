@@ -2,52 +2,114 @@
 """bench.py -- rays/s of the path-tracing hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[1] -- the reference's default scene
-(PT_CudaSimple/PathTracer.cu:48-69), default camera, 1920x1080, depth 10, seed 1337.  One step =
-one pass of the hot path over one batch: 64 more samples per pixel folded into the running mean
-(the reference's 64 BeginDrawing/FinalizeDrawing pairs), i.e. 2*N*64 = 265.4 M rays per GPU.
+With N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself (a `torch.distributed.run`
+child, before anything here touches a GPU) and passes rank 0's JSON line through; under an external
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one of the ranks.
+
+Workload (config.workload): BASELINE.json configs[1] -- the reference's default scene (PT_CudaSimple/PathTracer.cu:48-69),
+default camera, 1920x1080, depth 10, seed 1337.  One step = one pass of the hot path over one batch: 64 more samples per
+pixel folded into the running mean (the reference's 64 BeginDrawing/FinalizeDrawing pairs), 2*N*64 = 265.4 M rays per GPU.
 A "ray" is one extend-stage work item; the count comes from device counters.
 
-N > 1 is xGMI sample split with weak scaling: every rank renders 64 *different* samples per
-step of the same frame (strided RNG, stride 35 = reference-exact on this scene), then the ranks'
-running means are combined in a fixed pairwise order (all_to_all of image slices over RCCL ->
-tree combine kernel -> all_gather), so the image is bit-identical whatever N is.
+N > 1: sample split over xGMI, weak scaling (every rank renders 64 samples per step).  The frame's samples are dealt to
+8 VIRTUAL shards whatever N is (include/pt_plugin.h PT_SPLIT_SAMPLE; strided RNG, stride 35 = the reference's own stream
+on this scene), rank g renders the shards {v : v % N == g} into a running mean each, and ONE exchange inside the timed
+region -- after the last step, the shape of BASELINE.json configs[2]: render, then one reduce -- combines them over RCCL:
+all_to_all of image slices, the fixed-order tree over the 8 shards on each rank's slice, all_gather
+(pathtracer_amd/sample_split.py; --exchange native runs the C++ form, pt_dist_combine).  The image for a given total
+sample count is bit-identical on 1, 2, 4 and 8 GPUs (tests/test_sample_split_gloo.py, tests/test_gpu_split.py).
+--exchange-every E exchanges after every E-th step instead, beside the next step's render (a progressive display).
 
-The JSON line also carries `roofline` (algorithmic bytes of the dominant kernel / its device
-time measured with HIP events on the plugin's stream, against the 8 TB/s HBM peak) and
-`cpu_baseline` (the CPU oracle -- a port of the reference path -- timed on this box's cores).
+The JSON line carries `roofline` -- the bound that binds the dominant kernel: VALU issue, wave64 instructions per launch
+(rocprofv3 PMC, profiles/traffic.json, tied to the kernel sources by a hash) over the launch time measured here with HIP
+events on the plugin's stream -- `roofline_hbm` (SURVEY 8d's algorithmic bytes over the same time; not binding: the
+kernel keeps the path state in registers) and `cpu_baseline` (the CPU oracle, a port of the reference path, timed on this
+box's cores).  Outside the timed region it also measures a sustained loop, the wavefront engine, and one figure each for
+BASELINE.json's configs[4] (all materials) and configs[3] (10 092 triangles, BVH), each with its own bound.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # tests/scenes.py: the deterministic scenes of BASELINE.json's configs
 
 WIDTH, HEIGHT, SPP_PER_STEP, DEPTH = 1920, 1080, 64, 10
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles per SIMD at 2.4 GHz (same guide: v_fma_f32
 # 2 cycles on the SIMD-32; tools/valu_microbench.hip measures 2.4-2.6 at the clock the chip holds under load)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
-# SURVEY 8d algorithmic traffic of the wavefront formulation per pixel-sample on the default
-# scene: generate 52 + extend 36 + shade-diffuse 104 + extend 36 + shade-emissive 44*p +
-# accumulate 48 = 276 + 44 p bytes for 2 rays; p = share of secondary rays that reach the light
-# (measured by the oracle at 1080p: 0.0473).
+# SURVEY 8d algorithmic traffic of the wavefront formulation per pixel-sample on the default scene: generate 52 +
+# extend 36 + shade-diffuse 104 + extend 36 + shade-emissive 44*p + accumulate 48 = 276 + 44 p bytes for 2 rays;
+# p = share of secondary rays that reach the light (measured by the oracle at 1080p: 0.0473).
 P_LIGHT = 0.0473
 BYTES_PER_RAY = (276.0 + 44.0 * P_LIGHT) / 2.0
+KERNEL_SOURCES = ["pathtracer_amd/csrc/pt_kernels.hip", "pathtracer_amd/csrc/pt_device.hpp", "pathtracer_amd/csrc/pt_wavefront.hpp",
+                  "pathtracer_amd/csrc/pt_bvh.hpp"]
+
+# name -> (scene, depth, stride of the strided streams, description)
+WORKLOADS = {
+    "default": ("default", 10, 35, "reference default scene (BASELINE.json configs[1])"),
+    "c5": ("materials", 16, 2 + 33 * 16, "all materials, 48 triangles, depth 16 (BASELINE.json configs[4])"),
+    "c4_10k": ("synthetic10000", 10, 2 + 33 * 10, "synthetic 10 092 triangles through the BVH (BASELINE.json configs[3])"),
+}
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_counters():
+    """profiles/traffic.json: per (workload, engine) the wave64 VALU instructions and HBM bytes of ONE bench step, from
+    rocprofv3 --pmc passes (tools/measure_counters.sh), with the hash of the kernel sources they were taken on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def scene_of(name):
+    import scenes
+    if name == "default":
+        return scenes.default_scene()
+    if name == "materials":
+        return scenes.all_materials_scene()
+    if name.startswith("synthetic"):
+        return scenes.synthetic_scene(int(name[len("synthetic"):]))
+    raise ValueError(name)
+
+
+def launch_ranks(n, argv):
+    """--gpus N without a launcher: start the N ranks as a torch.distributed.run child.  Nothing in THIS process has
+    touched the GPU (no torch.cuda, no plugin call), and it replaces nothing: it waits and exits with the child's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(spp):
     """The oracle (kind 'port': our C restatement of the reference path) on the host cores: `spp` samples over all of
     them, and ('also report 1-thread') a twentieth of that on one thread."""
-    from oracle import pt_oracle_py as po
     import ctypes as C
+    import numpy as np
+    from oracle import pt_oracle_py as po
     po.lib()
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
     n = WIDTH * HEIGHT
@@ -74,11 +136,11 @@ def cpu_baseline(spp):
                            "sample": f"{one_spp} spp: {rays1} rays in {dt1:.2f} s"}}
 
 
-def parity_sample(tracer, w, h, spp_total, n_pixels=2048):
+def parity_sample(img, w, h, spp_total, n_pixels=2048):
     """BASELINE.json's third metric, 'RMSE vs reference': a bounded sample of pixels of the image the timed steps
     produced, against the oracle rendering the same pixels and samples (sequential RNG = the reference's stream)."""
+    import numpy as np
     from oracle import pt_oracle_py as po
-    img = tracer.readback()
     ids = np.unique(np.random.default_rng(7).integers(0, w * h, n_pixels)).astype(np.uint32)
     ref, _, _, _ = po.render(po.params(w, h, depth=DEPTH, spp=spp_total), pixel_ids=ids)
     got = img[ids]
@@ -89,19 +151,81 @@ def parity_sample(tracer, w, h, spp_total, n_pixels=2048):
             "max_rel_err": float(rel.max()), "spp": int(spp_total), "against": "oracle (CPU restatement of the reference path), same pixels and samples"}
 
 
+def valu_roofline(counters, key, kernel_ms, sha):
+    """The binding bound of these kernels: wave64 VALU instructions per step (PMC) / device time of the step."""
+    e = (counters.get("entries") or {}).get(key)
+    if not e or not e.get("valu_insts") or kernel_ms <= 0:
+        return None
+    ginst = e["valu_insts"] / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "valu", "achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave64-instructions/s",
+            "frac": round(ginst / VALU_PEAK_GINST, 4), "traffic": e.get("hbm_bytes"), "kernel": e.get("kernel"),
+            "kernel_ms": round(kernel_ms, 4), "instructions_per_launch": e["valu_insts"], "launches_per_step": e.get("launches_per_step", 1),
+            "lanes_per_instruction": e.get("lanes_per_instruction"),
+            "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE x2 / WRITE_SIZE, separate passes)",
+            "stale": counters.get("sha") != sha}
+
+
+def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples_per_pass=16, sequential=False, min_seconds=0.0, device=0):
+    """steps x (one pt_render of `spp` samples); returns wall ms per step, device ms per step, rays per step, the tracer's image"""
+    scene_name, depth, stride, _ = WORKLOADS[workload]
+    tracer = pt.PathTracer(w, h, device=device)
+    if scene_name != "default":
+        tracer.set_scene(*pt.make_scene(*scene_of(scene_name)))
+    eng = {"fused": pt.PT_ENGINE_FUSED, "wavefront": pt.PT_ENGINE_WAVEFRONT, "auto": pt.PT_ENGINE_AUTO}[engine]
+    if sequential:
+        tracer.set_options(engine=eng, depth=depth, samples_per_pass=samples_per_pass)
+    else:
+        tracer.set_options(engine=eng, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=samples_per_pass)
+    for _ in range(warmup):
+        tracer.render(spp)
+    st0 = tracer.stats()
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps or time.perf_counter() - t0 < min_seconds:
+        tracer.render(spp)
+        done += 1
+    dt = time.perf_counter() - t0
+    st = tracer.stats()
+    out = {"steps": done, "ms_per_step": dt / done * 1e3,
+           "kernel_ms": (st.total_render_ms - st0.total_render_ms) / max(1, st.renders - st0.renders),
+           "rays_per_step": (st.rays - st0.rays) / done, "engine_in_use": int(st.engine_in_use),
+           "rng": "sequential" if sequential else f"strided/{stride}", "depth": depth}
+    return out, tracer
+
+
+def side_figure(pt, counters, sha, workload, engine, w, h, steps=3, warmup=2):
+    """one figure of another BASELINE.json config, with its own bound (outside the timed region of the headline)"""
+    m, tracer = measure(pt, workload, engine, w, h, steps, warmup)
+    tracer.Destroy()
+    fig = {"workload": WORKLOADS[workload][3] + f", {w}x{h}, {SPP_PER_STEP} spp per step", "engine": engine, "rng": m["rng"], "depth": m["depth"],
+           "value": round(m["rays_per_step"] / (m["kernel_ms"] * 1e-3) / 1e6, 1), "unit": "Mrays/s (device time)",
+           "ms_per_step": round(m["ms_per_step"], 3), "kernel_ms": round(m["kernel_ms"], 3), "rays_per_step": int(m["rays_per_step"]),
+           "rays_per_pixel_sample": round(m["rays_per_step"] / (w * h * SPP_PER_STEP), 3)}
+    fig["roofline"] = valu_roofline(counters, f"{workload}/{engine}", m["kernel_ms"], sha)
+    return fig
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--engine", choices=["fused", "wavefront"], default="fused")
+    ap.add_argument("--engine", choices=["fused", "wavefront", "auto"], default="fused")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="default", help="N = 1 only: which BASELINE.json config the timed steps run (the headline is 'default')")
     ap.add_argument("--samples-per-pass", type=int, default=16, help="wavefront strided batching")
     ap.add_argument("--cpu-spp", type=int, default=48, help="samples of the CPU baseline leg (0 = skip); 48 spp at 1080p = 199 M rays, about 16 CPU-seconds over the box's 16 threads")
-    ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange even with one rank (self-test of the N>1 path)")
+    ap.add_argument("--bare", action="store_true", help="timed steps only: no CPU baseline, parity sample or side figures (profiling runs)")
+    ap.add_argument("--force-dist", action="store_true", help="run the sample split and its RCCL exchange even with one rank (self-test of the N>1 path)")
+    ap.add_argument("--exchange", choices=["torch", "native"], default="torch", help="N>1: torch.distributed collectives (RCCL) or the plugin's own pt_dist_combine (RCCL)")
+    ap.add_argument("--exchange-every", type=int, default=0, help="N>1: exchange after every E-th step, beside the next render; 0 = once, after the last step (inside the timed region)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np
     import torch
     import pathtracer_amd as pt
 
@@ -109,162 +233,196 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without a launcher")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        # The exchange must run BESIDE the next step's render, whose 8100 workgroups otherwise keep every CU slot: the
-        # collectives and the combine kernel go on high-priority streams (measured with one rank: 1413 -> 1340 us per
-        # step against 1322 us for the render alone)
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        pg_options = None
-        try:
-            pg_options = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-        except Exception:
-            pg_options = None
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=pg_options)
-
     w, h = args.width, args.height
     n_pix = w * h
-    engine = pt.PT_ENGINE_FUSED if args.engine == "fused" else pt.PT_ENGINE_WAVEFRONT
-    total_steps = args.warmup + args.steps
-    tracer = pt.PathTracer(w, h, device=local_rank)
-    if dist:
-        # rank r owns samples [r*S, (r+1)*S) of the frame, S = all its steps' samples
-        tracer.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, depth=DEPTH,
-                           samples_per_pass=args.samples_per_pass, sample_offset=rank * total_steps * SPP_PER_STEP)   # = sample_split.shard_samples
-    elif args.engine == "wavefront":
-        tracer.set_options(engine=engine, rng_mode=pt.PT_RNG_STRIDED, stride=35, depth=DEPTH, samples_per_pass=args.samples_per_pass)
-    else:
-        tracer.set_options(engine=engine, depth=DEPTH)
+    counters, sha = load_counters(), kernel_sources_sha()
     lib = pt.load_library()
 
-    exchange = None
-    if dist:
-        assert n_pix % world == 0, "image must split evenly over the ranks"
-        slice_floats = n_pix * 4 // world
-        # the exchange works on a snapshot of the running mean, so the next step's samples render (plugin
-        # stream) while RCCL moves the previous step's image (torch/RCCL streams)
-        snapshot = torch.empty(n_pix * 4, device="cuda", dtype=torch.float32)
-        gathered = torch.empty(world * slice_floats, device="cuda", dtype=torch.float32)   # shard-major slices
-        image = torch.empty(n_pix * 4, device="cuda", dtype=torch.float32)
-        my_slice = torch.empty(slice_floats, device="cuda", dtype=torch.float32)
-        tracer.set_options(samples_per_begin=SPP_PER_STEP)
+    if world == 1 and not args.force_dist:
+        # ------------------------------------------------------------------ one GPU
+        sequential = args.engine == "fused" and args.workload == "default"       # the reference's own streams
+        m, tracer = measure(pt, args.workload, args.engine, w, h, args.steps, args.warmup, samples_per_pass=args.samples_per_pass,
+                            sequential=sequential, device=local_rank)
+        torch.cuda.synchronize()
+        value = m["rays_per_step"] / (m["ms_per_step"] * 1e-3) / 1e6
+        hbm_achieved = m["rays_per_step"] * BYTES_PER_RAY / (m["kernel_ms"] * 1e-3) / 1e9
+        key = f"{args.workload}/{args.engine}"
+        roof = valu_roofline(counters, key, m["kernel_ms"], sha)
+        traffic = roof["traffic"] if roof else None
+        out = {
+            "metric": "Mrays/s (primary+bounce)", "value": round(value, 1), "unit": "Mrays/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(m["ms_per_step"], 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "spp_per_s": round(SPP_PER_STEP / (m["ms_per_step"] * 1e-3), 1),
+            "config": {"workload": f"{WORKLOADS[args.workload][3]}, {w}x{h}, {SPP_PER_STEP} spp per step per GPU, depth {m['depth']}, seed 1337",
+                       "engine": args.engine, "rng": m["rng"], "parallelism": "single GPU"},
+            "roofline": roof,
+        }
+        if args.workload == "default":
+            out["roofline_hbm"] = {"bound": "hbm", "binding": False, "achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(hbm_achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                   "measured_frac": round(traffic / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                                   "algorithmic_bytes_per_ray": round(BYTES_PER_RAY, 2), "rays_per_launch": int(m["rays_per_step"]),
+                                   "note": "SURVEY 8d's byte model prices the wavefront formulation's queue traffic; these kernels keep the path state in registers, "
+                                           "so achieved/peak > 1 only says that traffic is gone (measured_frac = PMC bytes / time / peak)"}
+        if not args.bare:
+            if args.workload == "default" and sequential:
+                out["parity"] = parity_sample(tracer.readback(), w, h, (args.warmup + m["steps"]) * SPP_PER_STEP)
+            tracer.Destroy()
+            try:
+                with open(os.path.join(ROOT, "profiles", "tolerance.json")) as f:
+                    out["tolerance"] = json.load(f)       # tools/fma_tolerance.py: the oracle built with FMA contraction against the strict one
+            except Exception:
+                pass
+            # outside the timed region: a sustained loop of the same step, the other engine, the other configs
+            ms, t2 = measure(pt, args.workload, args.engine, w, h, 1, 1, samples_per_pass=args.samples_per_pass, sequential=sequential, min_seconds=2.5, device=local_rank)
+            t2.Destroy()
+            out["sustained_ms_per_step"] = round(ms["ms_per_step"], 4)
+            out["sustained"] = {"steps": ms["steps"], "seconds": round(ms["ms_per_step"] * ms["steps"] / 1e3, 2), "kernel_ms": round(ms["kernel_ms"], 4),
+                                "value": round(ms["rays_per_step"] / (ms["ms_per_step"] * 1e-3) / 1e6, 1)}
+            figures = []
+            other = "wavefront" if args.engine != "wavefront" else "fused"
+            figures.append(side_figure(pt, counters, sha, args.workload, other, w, h, steps=10, warmup=3))
+            ma, ta = measure(pt, args.workload, "auto", w, h, 3, 3, samples_per_pass=args.samples_per_pass, sequential=sequential, device=local_rank)
+            ta.Destroy()
+            out["engine_auto_pick"] = {pt.PT_ENGINE_FUSED: "fused", pt.PT_ENGINE_WAVEFRONT: "wavefront"}.get(ma["engine_in_use"], "undecided")
+            if args.workload == "default":
+                for wl, eng in (("c5", "wavefront"), ("c5", "fused"), ("c4_10k", "wavefront"), ("c4_10k", "fused")):
+                    figures.append(side_figure(pt, counters, sha, wl, eng, w, h))
+            out["other_figures"] = figures
+            out["cpu_baseline"] = cpu_baseline(args.cpu_spp) if args.cpu_spp > 0 else None
+        else:
+            tracer.Destroy()
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+        return
+
+    # ---------------------------------------------------------------------- sample split over `world` ranks
+    import torch.distributed as dist
+    from pathtracer_amd import sample_split as ss
+    if "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    if ss.VIRTUAL_SHARDS % world:
+        raise SystemExit(f"sample split deals the frame to {ss.VIRTUAL_SHARDS} virtual shards: --gpus must divide it (1, 2, 4, 8)")
+    # the exchange runs BESIDE a render when --exchange-every is used: collectives and combine on high-priority streams
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+    pg_options = None
+    try:
+        pg_options = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:
+        pg_options = None
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=pg_options)
+    ones = torch.ones(1, device="cuda")
+    dist.all_reduce(ones)                                    # RCCL is up and saw every rank
+    rccl_ranks = int(ones.item())
+
+    n_local = ss.VIRTUAL_SHARDS // world
+    per_shard = SPP_PER_STEP // n_local                       # samples each local shard gets per step: 64 per rank and step in all
+    assert per_shard * n_local == SPP_PER_STEP
+    tracer = pt.PathTracer(w, h, device=local_rank)
+    tracer.set_options(engine=pt.PT_ENGINE_FUSED if args.engine != "wavefront" else pt.PT_ENGINE_WAVEFRONT, depth=DEPTH,
+                       rng_mode=pt.PT_RNG_STRIDED, stride=35, samples_per_pass=args.samples_per_pass, samples_per_begin=per_shard,
+                       split_mode=pt.PT_SPLIT_SAMPLE, split_rank=rank, split_ranks=world)
+    local, pitch, vshards = tracer.shard_layout()
+    assert (local, vshards) == (n_local, ss.VIRTUAL_SHARDS) and pitch == ss.slice_pixels(n_pix, world) * world
+    slice_px = pitch // world
+    native = args.exchange == "native"
+    if native:
+        ids = [pt.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)                # the id travels by the host's own means: here torch's store
+        tracer.dist_init(ids[0])
+    else:
+        snapshot = torch.empty(local * pitch * 4, device="cuda", dtype=torch.float32)     # this rank's shard means
+        stacked = torch.empty(vshards * slice_px * 4, device="cuda", dtype=torch.float32)
+        image = torch.empty(pitch * 4, device="cuda", dtype=torch.float32)
         plugin_stream = torch.cuda.ExternalStream(tracer.stream())
         exchange_stream = torch.cuda.Stream(priority=-1)
-        exchanged = torch.cuda.Event()
+        snapshot_ready, exchanged = torch.cuda.Event(), torch.cuda.Event()
 
-        from pathtracer_amd import sample_split
-
-        def combine_slices(stacked, shards, n_pix_slice, out_slice):
-            rc = lib.pt_hip_combine_shards(stacked.data_ptr(), shards, n_pix_slice, out_slice.data_ptr(),
-                                           exchange_stream.cuda_stream)
+        def combine_slices(stk, shards, n_pix_slice, out_slice):
+            rc = lib.pt_hip_combine_shards(stk.data_ptr(), shards, n_pix_slice, out_slice.data_ptr(), torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.pt_hip_last_error()
 
-        def exchange():
-            # all_to_all of image slices -> fixed-order tree on this rank's slice -> all_gather; enqueued, not awaited
-            with torch.cuda.stream(exchange_stream):
-                sample_split.exchange_and_combine(snapshot, dist, combine_slices, out=image, scratch=gathered, slice_out=my_slice)
+    exchanges = 0
 
-    def step():
-        if not exchange:
-            tracer.render(SPP_PER_STEP)                       # blocks until the samples are in the mean
+    def exchange():
+        """enqueue the one exchange for the shard means as they are now; nothing is awaited (torch) / returns done (native)"""
+        nonlocal exchanges
+        exchanges += 1
+        if native:
+            tracer.dist_combine()
             return
-        # one step = 64 more samples into this rank's mean + one exchange of a whole image.  Enqueue order: the
-        # render (plugin stream; BeginDrawing returns at once), the exchange of the PREVIOUS step's snapshot beside
-        # it (torch/RCCL streams), then -- on the plugin stream, behind both -- the copy of the new mean into the
-        # snapshot; FinalizeDrawing is the step's one host wait.
-        tracer.BeginDrawing()
-        exchange()
+        plugin_stream.wait_event(exchanged)                       # the previous exchange has read the snapshot
+        tracer.copy_mean_async(snapshot.data_ptr(), snapshot.numel())
+        snapshot_ready.record(plugin_stream)
+        exchange_stream.wait_event(snapshot_ready)
+        with torch.cuda.stream(exchange_stream):
+            ss.exchange_and_combine(snapshot, dist, combine_slices, stacked, image)
         exchanged.record(exchange_stream)
-        plugin_stream.wait_event(exchanged)                   # the snapshot is free to overwrite
-        tracer.copy_mean_async(snapshot.data_ptr(), n_pix * 4)
+
+    def step(k):
+        tracer.BeginDrawing()                                     # this rank's 64 samples of the step, enqueued
         tracer.FinalizeDrawing()
+        if args.exchange_every and (k + 1) % args.exchange_every == 0:
+            exchange()
 
     def sync():
         torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
 
-    if exchange:
-        tracer.copy_mean(snapshot.data_ptr(), n_pix * 4)       # the first step exchanges the (empty) start image
-    for _ in range(args.warmup):
-        step()
+    if not native:
+        exchanged.record(exchange_stream)
+    for k in range(args.warmup):
+        step(k)
+    exchange()                                                    # warm the collectives up too
     sync()
     st0 = tracer.stats()
-    rays0, ms0, renders0 = st0.rays, st0.total_render_ms, st0.renders
+    exchanges = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
+    if not args.exchange_every or args.steps % args.exchange_every:
+        exchange()                                                # the render's one reduce (configs[2]'s shape)
     sync()
     dt = time.perf_counter() - t0
     st = tracer.stats()
-    rays_rank = st.rays - rays0
-    # average device time of one render = one k_fused launch (or one wavefront pass sequence):
-    # HIP events recorded around it on the plugin's own stream
-    last_ms = (st.total_render_ms - ms0) / max(1, st.renders - renders0)
-
-    if dist:
-        t = torch.tensor([dt, float(rays_rank)], device="cuda", dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, rays_total = float(tmax[0]), float(t[1])
-    else:
-        rays_total = float(rays_rank)
+    rays_rank = st.rays - st0.rays
+    kernel_ms = (st.total_render_ms - st0.total_render_ms) / max(1, st.renders - st0.renders)
+    t = torch.tensor([dt, float(rays_rank)], device="cuda", dtype=torch.float64)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dt, rays_total = float(tmax[0]), float(t[1])
+    # every rank holds the same image: a checksum of checksums over the ranks
+    img = tracer.readback() if native else image[:n_pix * 4].cpu().numpy().reshape(n_pix, 4)
+    digest = int(np.bitwise_xor.reduce(img.view(np.uint32).reshape(-1)))
+    dg = torch.tensor([digest, -digest], device="cuda", dtype=torch.int64)
+    dist.all_reduce(dg, op=dist.ReduceOp.MAX)
+    same_image = int(dg[0]) == -int(dg[1])
 
     if rank == 0:
-        rays_per_launch = rays_rank / max(1, args.steps)
-        achieved = rays_per_launch * BYTES_PER_RAY / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0
-        traffic = valu_insts = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                pmc = json.load(open(tpath))
-                traffic = pmc.get(f"{args.engine}_{w}x{h}_{SPP_PER_STEP}spp")
-                valu_insts = pmc.get(f"{args.engine}_{w}x{h}_{SPP_PER_STEP}spp_valu_insts")
-            except Exception:
-                traffic = valu_insts = None
+        roof = valu_roofline(counters, f"default/{'wavefront' if args.engine == 'wavefront' else 'fused'}_strided", kernel_ms, sha) or \
+               valu_roofline(counters, f"default/{'wavefront' if args.engine == 'wavefront' else 'fused'}", kernel_ms, sha)
         out = {
-            "metric": "Mrays/s (primary+bounce)",
-            "value": round(rays_total / dt / 1e6, 1),
-            "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "metric": "Mrays/s (primary+bounce)", "value": round(rays_total / dt / 1e6, 1), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "spp_per_s": round(SPP_PER_STEP * world * args.steps / dt, 1),
-            "config": {"workload": f"reference default scene {w}x{h}, {SPP_PER_STEP} spp per step per GPU, depth {DEPTH}, seed 1337 "
-                                   f"(BASELINE.json configs[1])",
-                       "engine": args.engine, "rng": "sequential" if (not dist and args.engine == "fused") else "strided/35",
-                       "parallelism": "single GPU" if not dist else f"sample split x{world}, fixed-order combine over RCCL (all_to_all + all_gather), overlapped with the next step"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_fused" if args.engine == "fused" else "wavefront step: 4 passes of 16 spp, one k_bounces launch each (camera rays + bounce loop + fold)",
-                         "kernel_ms": round(last_ms, 4), "algorithmic_bytes_per_ray": round(BYTES_PER_RAY, 2),
-                         "rays_per_launch": int(rays_per_launch)},
+            "config": {"workload": f"{WORKLOADS['default'][3]}, {w}x{h}, {SPP_PER_STEP} spp per step per GPU, depth {DEPTH}, seed 1337",
+                       "engine": "wavefront" if args.engine == "wavefront" else "fused", "rng": "strided/35",
+                       "parallelism": f"sample split x{world}: {ss.VIRTUAL_SHARDS} virtual shards, {n_local} per rank, {per_shard} spp per shard and step; "
+                                      f"{exchanges} exchange(s) in the timed region ({'pt_dist_combine' if native else 'torch.distributed'} over RCCL: all_to_all of slices, fixed-order tree, all_gather)"},
+            "rccl_ranks": rccl_ranks, "exchanges_timed": exchanges, "image_identical_on_all_ranks": same_image,
+            "kernel_ms_per_step": round(kernel_ms, 4),
+            "roofline": roof, "cpu_baseline": None,
         }
-        if valu_insts and last_ms > 0:
-            # the fused kernel moves 0.3 B per ray, so the HBM figure above only says that the wavefront formulation's
-            # traffic is gone; what bounds it is VALU issue: wave64 instructions per launch (PMC, profiles/) / launch time
-            ginst = valu_insts / (last_ms * 1e-3) / 1e9
-            out["roofline_valu"] = {"bound": "valu", "achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave64-instructions/s",
-                                    "frac": round(ginst / VALU_PEAK_GINST, 4), "instructions_per_launch": valu_insts}
-        if world == 1 and not dist and args.engine == "fused" and args.cpu_spp > 0:
-            out["parity"] = parity_sample(tracer, w, h, total_steps * SPP_PER_STEP)
-        if world == 1 and args.cpu_spp > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_spp)
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     tracer.Destroy()
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

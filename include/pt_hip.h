@@ -89,10 +89,14 @@ typedef struct {
     pt_float4 origin, top_left, bottom_left, bottom_right;  /* Camera.h:49-77 */
 } pt_frame;
 
-/* Counters a render adds to (device side, 8-byte aligned, PT_STATS_WORDS uint64 words):
+/* Counters a render adds to (device side, 8-byte aligned, PT_STATS_WORDS uint64 words, zeroed once by the caller):
  * [0] rays = extend-stage work items, [1] diffuse bounces shaded,
- * [2] paths generated, [3] reserved, [4+b] rays at bounce b. */
-#define PT_STATS_WORDS (4 + PT_MAX_DEPTH)
+ * [2] paths generated, [3] reserved, [4+b] rays at bounce b (wavefront engine);
+ * from PT_STATS_PUBLIC_WORDS on: partial sums the kernels spread their atomics over (a single counter word sustains
+ * ~88 atomics per microsecond on MI355X); they are folded into [0..1] and zeroed again before a render call's work
+ * on the stream ends, so a reader only ever looks at the first PT_STATS_PUBLIC_WORDS words. */
+#define PT_STATS_PUBLIC_WORDS 64
+#define PT_STATS_WORDS (PT_STATS_PUBLIC_WORDS + 32 * 16)
 
 const char* pt_hip_last_error(void);
 

@@ -30,7 +30,8 @@ PT_SHADING_REFERENCE, PT_SHADING_EXTENDED = 0, 1
 PT_FRAME_FAST_DIV = 1
 PT_FRAME_SCENE_BVH = 2
 PT_MAX_DEPTH = 32
-PT_STATS_WORDS = 4 + PT_MAX_DEPTH
+PT_STATS_PUBLIC_WORDS = 64
+PT_STATS_WORDS = PT_STATS_PUBLIC_WORDS + 32 * 16
 PT_NOALLOC_SCRATCH_BYTES = 64 << 20
 
 

@@ -36,6 +36,8 @@ using namespace ptd;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kStatsSlots = 32, kStatsSlotWords = 16;      // k_fused's partial counters: 32 slots, one 128-byte line each
+static_assert(PT_STATS_WORDS == PT_STATS_PUBLIC_WORDS + kStatsSlots * kStatsSlotWords, "pt_hip.h sizes the statistics array for the partial sums");
 static_assert(kBlock == (int)kQueueBlock, "pt_device.hpp lays the traversal stack and the queue rows out for 256-lane blocks");
 constexpr uint32_t kLdsTriChunk = 1024;                 // 64 KiB of packed triangles per stage
 constexpr uint32_t kShadeLdsMaxTris = 1536;             // shade keeps triangles + materials in LDS up to here
@@ -506,17 +508,44 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 1 : 8) void k_fused(FrameDev f
 		if (!STRIDED) rng_io[li] = rng;
 	}
 	if (stats) {
-		// wave reduce, one 64-bit atomic per wave per counter
+		// wave reduce -> block reduce in LDS -> ONE pair of global atomics per block, into one of kStatsSlots partial sums that
+		// sit 128 bytes apart (k_fold_partials adds them into stats[0..1] afterwards).  A same-address atomic per wave was the
+		// floor of this kernel: 64 800 of them at the ~88 per microsecond one word sustains = 0.74 ms per launch, whatever
+		// the sample count (measured: 0.79 ms for 1 spp, 0.81 for 8, 1.12 for 64).
+		__shared__ unsigned long long s_cnt[2];
+		if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+		__syncthreads();
 		for (int off = 32; off > 0; off >>= 1) {
 			n_rays += __shfl_down(n_rays, off, 64);
 			n_diffuse += __shfl_down(n_diffuse, off, 64);
 		}
 		if ((threadIdx.x & 63) == 0) {
-			atomicAdd(&stats[0], (unsigned long long)n_rays);
-			atomicAdd(&stats[1], (unsigned long long)n_diffuse);
+			atomicAdd(&s_cnt[0], (unsigned long long)n_rays);
+			atomicAdd(&s_cnt[1], (unsigned long long)n_diffuse);
 		}
-		if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_samples * f.pixel_count);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long* slot = stats + PT_STATS_PUBLIC_WORDS + (size_t)(blockIdx.x % kStatsSlots) * kStatsSlotWords;
+			atomicAdd(&slot[0], s_cnt[0]);
+			atomicAdd(&slot[1], s_cnt[1]);
+			if (blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_samples * f.pixel_count);
+		}
 	}
+}
+
+// stats[0..1] += the partial sums of k_fused, which are zeroed for the next launch (one wave)
+__global__ void k_fold_partials(unsigned long long* __restrict__ stats) {
+	unsigned long long rays = 0, diffuse = 0;
+	if (threadIdx.x < kStatsSlots) {
+		unsigned long long* slot = stats + PT_STATS_PUBLIC_WORDS + (size_t)threadIdx.x * kStatsSlotWords;
+		rays = slot[0]; diffuse = slot[1];
+		slot[0] = 0; slot[1] = 0;
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		rays += __shfl_down(rays, off, 64);
+		diffuse += __shfl_down(diffuse, off, 64);
+	}
+	if (threadIdx.x == 0) { atomicAdd(&stats[0], rays); atomicAdd(&stats[1], diffuse); }
 }
 
 // Sample-split combine: ((m0+m1)+(m2+m3))+... then * 1/shards, per float lane.
@@ -1105,6 +1134,7 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	if (strided) { if (mode == 2) PT_FUSED(true, 2); else if (mode == 1) PT_FUSED(true, 1); else PT_FUSED(true, 0); }
 	else { if (mode == 2) PT_FUSED(false, 2); else if (mode == 1) PT_FUSED(false, 1); else PT_FUSED(false, 0); }
 #undef PT_FUSED
+	if (stats) hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (unsigned long long*)stats);
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }

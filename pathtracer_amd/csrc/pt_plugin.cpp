@@ -370,7 +370,7 @@ public:
 		if (_error) return _error;
 		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
-		uint64_t words[PT_STATS_WORDS];
+		uint64_t words[PT_STATS_PUBLIC_WORDS];
 		PT_TRY(pt_hip_memcpy_d2h(words, _dev.stats, sizeof(words), _stream));
 		std::memset(out, 0, sizeof(*out));
 		out->rays = words[0]; out->diffuse_bounces = words[1]; out->paths = words[2];
