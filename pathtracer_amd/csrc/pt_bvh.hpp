@@ -63,7 +63,34 @@ static_assert(sizeof(QNode) == 32, "quantised BVH node is 2 x 16 bytes");
 // 64 bytes: what the leaf test needs, in BVH order.  {v0.xyz, e0.x} {e0.yz, e1.xy} {e1.z, orig index bits, 0, 0} {pad}
 struct LeafTri { float f[16]; };
 
+// ---- normal classes: a tight inflation for rays that graze nothing ----
+// The worst case kappa_i * S above (det barely above EPSILON) belongs to a GRAZING ray: det_true = |d| |e0||e1| sin(phi)
+// |cos(theta)| (phi between the edges, theta between ray and normal).  If |cos(theta)| >= kRho and sin(phi) >= kSinFloor
+// the same term-by-term bound reads
+//     delta <= 7 * eps * S / (kRho * sin(phi))  <=  kKappaLo * S,     kKappaLo = 11 * eps / (kRho * kSinFloor)
+// whatever the triangle's size (no EPSILON in it: det_true is bounded directly) -- 1.3e-4 * S against 7e-3 * S for the
+// quads of the 10 092-triangle scene, whose boxes the worst case makes half as wide again.
+// So the builder sorts the triangles' planes (normals, sign-agnostic) into at most kMaxClasses classes, each a cone
+// {axis, tau = sin(half-angle + asin(kRho)) with margins}: a ray with |dhat . axis| >= tau is at least asin(kRho) away
+// from grazing EVERY triangle of the class.  A ray that passes this test for all classes of a scene whose triangles all
+// belong to one ("calm" ray: 94 % of the rays in an axis-aligned room) inflates every box by kKappaLo * S only; any other
+// ray, and every ray of a scene with slivers or more plane directions than classes, keeps the worst case as before.
+constexpr float kRho = 0.02f;                      // |cos(ray, normal)| from which a hit counts as "not grazing"
+constexpr float kSinFloor = 0.25f;                 // triangles whose edges e0, e1 are closer to parallel than this are never classified
+constexpr float kKappaLo = 11.0f * kEps32 / (kRho * kSinFloor);      // == ptd::kBvhKappaLo
+constexpr uint32_t kMaxClasses = 8;                // == ptd::kBvhMaxClasses
+constexpr double kClassAngle = 0.14;               // radians (8 degrees): how far a normal may be from its class's axis
+
+struct NormalClass { float axis[3], tau; };        // 16 bytes, what the traversal reads
+struct ClassBlock {                                // 192 bytes at the end of the BVH part of the blob
+	uint32_t n_classes, all_classified, _pad[2];
+	NormalClass cls[kMaxClasses];
+	uint32_t _pad2[12];
+};
+static_assert(sizeof(ClassBlock) == 192, "class block is 192 bytes");
+
 struct Built {
+	ClassBlock classes{};
 	std::vector<Node> nodes;
 	std::vector<LeafTri> tris;
 	float center[3] = { 0, 0, 0 };
@@ -73,6 +100,44 @@ struct Built {
 };
 
 struct Prim { float lo[3], hi[3], c[3]; float kappa; uint32_t idx; };
+
+// Greedy classification of the triangles' unit normals n (double, sign-agnostic); sliver[i]: never classified.
+inline ClassBlock classify_normals(const std::vector<double>& n, const std::vector<char>& sliver) {
+	ClassBlock out{};
+	const size_t count = sliver.size();
+	double axes[kMaxClasses][3];
+	double cos_h[kMaxClasses];
+	uint32_t k_used = 0;
+	bool all = true;
+	const double cos_accept = std::cos(kClassAngle);
+	for (size_t i = 0; i < count; i++) {
+		if (sliver[i]) { all = false; continue; }
+		const double* ni = &n[3 * i];
+		bool placed = false;
+		for (uint32_t k = 0; k < k_used && !placed; k++) {
+			double c = std::fabs(ni[0] * axes[k][0] + ni[1] * axes[k][1] + ni[2] * axes[k][2]);
+			if (c >= cos_accept) { cos_h[k] = std::min(cos_h[k], c); placed = true; }
+		}
+		if (!placed) {
+			if (k_used == kMaxClasses) { all = false; continue; }
+			for (int c = 0; c < 3; c++) axes[k_used][c] = ni[c];
+			cos_h[k_used] = 1.0;
+			k_used++;
+		}
+	}
+	// (a triangle that found no class leaves `all` false: its plane is covered by nothing, so no ray may be called calm)
+	out.n_classes = k_used;
+	out.all_classified = (all && count > 0) ? 1u : 0u;
+	for (uint32_t k = 0; k < k_used; k++) {
+		float axf[3] = { (float)axes[k][0], (float)axes[k][1], (float)axes[k][2] };      // the traversal uses the rounded axis: measure against it
+		double alen = std::sqrt((double)axf[0] * axf[0] + (double)axf[1] * axf[1] + (double)axf[2] * axf[2]);
+		// members were accepted against the double axis; the float axis differs by < 1e-7 rad, the 1e-3 rad below covers it
+		double angle = std::acos(std::min(1.0, cos_h[k])) + std::asin((double)kRho) + 1e-3;
+		for (int c = 0; c < 3; c++) out.cls[k].axis[c] = axf[c];
+		out.cls[k].tau = (float)(std::sin(angle) * alen * 1.0001 + 1e-5);     // |dhat . axf| = |axf| |cos|: alen folds the axis' own length in
+	}
+	return out;
+}
 
 // x on the grid {glo + q * cell}: the largest q with glo + q*cell <= x (down) / the smallest with glo + q*cell >= x (up),
 // in double against the float grid the device uses, clamped to 16 bits (a clamped corner only happens for the far-away
@@ -261,6 +326,8 @@ inline uint32_t inner_depth(const std::vector<Node>& nodes) {
 inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, uint32_t stack_depth) {
 	Built out;
 	std::vector<Prim> prims(n_tris);
+	std::vector<double> normals((size_t)n_tris * 3);
+	std::vector<char> sliver(n_tris);
 	float slo[3] = { INFINITY, INFINITY, INFINITY }, shi[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (uint32_t i = 0; i < n_tris; i++) {
 		const pt_float4* P[3] = { &v[t[i].vertexIdx0].position, &v[t[i].vertexIdx1].position, &v[t[i].vertexIdx2].position };
@@ -283,7 +350,17 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, ui
 		float l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
 		out.max_edge = std::max(out.max_edge, std::max(l0, std::max(l1, l2)));
 		pr.idx = i;
+		{
+			double a0[3] = { (double)P[1]->x - P[0]->x, (double)P[1]->y - P[0]->y, (double)P[1]->z - P[0]->z };
+			double a1[3] = { (double)P[2]->x - P[0]->x, (double)P[2]->y - P[0]->y, (double)P[2]->z - P[0]->z };
+			double nx = a0[1] * a1[2] - a0[2] * a1[1], ny = a0[2] * a1[0] - a0[0] * a1[2], nz = a0[0] * a1[1] - a0[1] * a1[0];
+			double nl = std::sqrt(nx * nx + ny * ny + nz * nz);
+			double ll = std::sqrt(a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2]) * std::sqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+			sliver[i] = !(nl > 0.0) || !(ll > 0.0) || !std::isfinite(nl) || !std::isfinite(ll) || nl / ll < 1.02 * (double)kSinFloor;     // sin(phi) = |e0 x e1| / (|e0||e1|)
+			normals[3 * (size_t)i + 0] = nl > 0.0 ? nx / nl : 0.0; normals[3 * (size_t)i + 1] = nl > 0.0 ? ny / nl : 0.0; normals[3 * (size_t)i + 2] = nl > 0.0 ? nz / nl : 0.0;
+		}
 	}
+	out.classes = classify_normals(normals, sliver);
 	float r2 = 0.0f;
 	for (int k = 0; k < 3; k++) {
 		out.center[k] = n_tris ? 0.5f * (slo[k] + shi[k]) : 0.0f;

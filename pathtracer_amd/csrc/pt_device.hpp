@@ -184,7 +184,10 @@ __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 	return (d < 1u ? 1u : d) + kBvhDepthSlack;
 }
 
-constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records
+constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block
+constexpr uint32_t kBvhClassBytes = 192;    // pt_bvh.hpp ClassBlock
+constexpr uint32_t kBvhMaxClasses = 8;      // == ptbvh::kMaxClasses
+constexpr float kBvhKappaLo = 11.0f * 5.9604645e-8f / (0.02f * 0.25f);     // == ptbvh::kKappaLo: inflation per unit of S for a ray that grazes nothing
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
@@ -296,6 +299,8 @@ struct BvhView {
 	float max_edge;          // longest triangle edge
 	bool det_bounded;        // SceneHeader::flags bit 0
 	int stack_depth;         // bvh_stack_depth(n_tris)
+	const float4* classes;   // pt_bvh.hpp NormalClass {axis, tau} x n_classes (wave-uniform reads)
+	uint32_t n_classes;      // 0: no ray is ever "calm" (slivers, or more plane directions than classes)
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -319,8 +324,20 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	v.max_edge = hdr->max_edge;
 	v.det_bounded = (hdr->flags & kSceneDetBounded) != 0;
 	v.stack_depth = (int)bvh_stack_depth(n_tris);
+	const uint32_t* cb = reinterpret_cast<const uint32_t*>(scene + off + (size_t)n_tris * (kBvhNodeBytes + 64u));
+	v.n_classes = cb[1] != 0u ? (cb[0] < kBvhMaxClasses ? cb[0] : kBvhMaxClasses) : 0u;      // {n_classes, all_classified, ..}
+	v.classes = reinterpret_cast<const float4*>(cb + 4);
 	return v;
 }
+
+#ifdef PT_BVH_COUNT
+// debug build only (tools/bvh_counts.py): lane- and wave-level work counters of the traversal
+__device__ unsigned long long g_bvh_count[8];
+#define PT_COUNT(i, v) atomicAdd(&g_bvh_count[i], (unsigned long long)(v))
+#define PT_COUNT_WAVE(pred, lanes, trips) do { unsigned long long w_ = __ballot(pred); if (w_ && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(w_)) { PT_COUNT(lanes, __popcll(w_)); PT_COUNT(trips, 1); } } while (0)
+#else
+#define PT_COUNT_WAVE(pred, lanes, trips) ((void)0)
+#endif
 
 // Slab test of one child box in grid units.  ol / oh = the ray origin on the grid plus / minus the inflation, so
 // (l - ol) = (l - infl) - o and (h - oh) = (h + infl) - o; inv = cell / direction; [tlo, thi] is the (widened) ray interval.
@@ -340,6 +357,7 @@ __device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint
                                          float& best_t, uint32_t& hit_tri) {
 	uint32_t first = code >> 3, count = (code & 7u) + 1u;
 	for (uint32_t k = 0; k < count; k++) {
+		PT_COUNT_WAVE(true, 2, 3);
 		const float4* rec = leaves + (size_t)(first + k) * 4;
 		float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
 		float t;
@@ -393,13 +411,25 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	float delta_max = bv.kappa_root * bv.s_bound + bv.slack;
 	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
 	float delta_root = bv.kappa_root * s_ray + bv.slack;     // how far outside its triangle an accepted hit can be
-	r.dt = 1.01f * delta_root / dlen;                        // ... in ray-parameter units
+	r.dt = 1.01f * delta_root / dlen;                        // ... in ray-parameter units (the worst case for every ray: it only widens [tlo, thi])
 	r.tlo = -r.dt;
+	// A "calm" ray -- at least asin(kRho) away from grazing every triangle of the scene (pt_bvh.hpp, normal classes) -- needs
+	// only the size-independent inflation for the boxes.  dhat to ~1e-6 (v_rcp): tau carries 1e-4 relative + 1e-5 for it.
+	bool calm = bv.n_classes != 0u;
+	{
+		float il = __builtin_amdgcn_rcpf(dlen);
+		Vec3 dh{ dd.x * il, dd.y * il, dd.z * il };
+		for (uint32_t k = 0; k < bv.n_classes; k++) {
+			float4 c = bv.classes[k];
+			calm = calm && fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) >= c.w;
+		}
+	}
+	float delta_box = calm ? fminf(kBvhKappaLo, bv.kappa_root) * s_ray + bv.slack : delta_root;
 	// The origin in grid units.  Its own rounding (a subtraction, a product with the rounded 1/cell: under 4 ulp of a
 	// value that can reach 65535 + the camera's distance) and that of the slab's (q - o) go into the inflation, four
 	// times over: 1e-6 of the magnitudes involved -- hundredths of a cell, against boxes tens of cells wide.
 	Vec3 og{ (o.x - bv.glo.x) * bv.inv_cell, (o.y - bv.glo.y) * bv.inv_cell, (o.z - bv.glo.z) * bv.inv_cell };
-	float infl = 1.00001f * (delta_root * bv.inv_cell) + 1e-6f * (65536.0f + fabsf(og.x) + fabsf(og.y) + fabsf(og.z));
+	float infl = 1.00001f * (delta_box * bv.inv_cell) + 1e-6f * (65536.0f + fabsf(og.x) + fabsf(og.y) + fabsf(og.z));
 	r.ol = Vec3{ og.x + infl, og.y + infl, og.z + infl };
 	r.oh = Vec3{ og.x - infl, og.y - infl, og.z - infl };
 	return r;
@@ -430,9 +460,16 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 			int leafy = __popcll(__ballot(cur < 0));
 			if (leafy > 0 && (__popcll(walking) < kBvhQuorum || (PT_BVH_RATIO > 0 && __popcll(walking) * PT_BVH_RATIO < leafy * 4))) break;
 		}
+		PT_COUNT_WAVE((uint32_t)cur < (uint32_t)kBvhDone, 0, 1);
 		if ((uint32_t)cur < (uint32_t)kBvhDone) {
 			const uint4* n = bv.nodes + (size_t)cur * 2;
 			uint4 w0 = n[0], w1 = n[1];
+#ifdef PT_EXP_EXTRA_LOAD
+			{ uint4 x = bv.nodes[(size_t)(cur ^ 5) * 2]; if ((x.x ^ x.y ^ x.z ^ x.w) == 0x12345677u) best_t = 0.0f; }     // sensitivity experiment: +1 load per node step
+#endif
+#ifdef PT_EXP_EXTRA_VALU
+			{ float x = __uint_as_float(w0.x); for (int k = 0; k < PT_EXP_EXTRA_VALU; k++) x = __builtin_fmaf(x, 1.0001f, 0.5f); if (x == 1.2345f) best_t = 0.0f; }
+#endif
 			int32_t c0 = (int32_t)w1.z, c1 = (int32_t)w1.w;
 			float thi = best_t + r.dt + 1e-6f * best_t;
 			float tn0, tn1;

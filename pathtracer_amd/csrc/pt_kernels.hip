@@ -759,7 +759,7 @@ int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_tria
 size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
 	size_t n = bvh_offset_of(n_triangles, n_materials);
 	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B
-	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u);
+	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes;
 	return n;
 }
 
@@ -809,6 +809,9 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			std::vector<ptbvh::QNode> qnodes = ptbvh::quantize(bvh.nodes, glo, cell);
 			std::memcpy(base + hdr.bvh_offset, qnodes.data(), qnodes.size() * sizeof(ptbvh::QNode));
 			std::memcpy(base + hdr.leaf_offset, bvh.tris.data(), bvh.tris.size() * sizeof(ptbvh::LeafTri));
+			static_assert(sizeof(ptbvh::ClassBlock) == kBvhClassBytes && ptbvh::kMaxClasses == kBvhMaxClasses && ptbvh::kKappaLo == kBvhKappaLo,
+			              "pt_bvh.hpp and pt_device.hpp disagree on the normal classes");
+			std::memcpy(base + hdr.leaf_offset + (size_t)n_triangles * 64u, &bvh.classes, sizeof(bvh.classes));
 			for (int k = 0; k < 3; k++) hdr.center[k] = bvh.center[k];
 			hdr.radius = bvh.radius;
 			hdr.kappa_root = bvh.kappa_root;
@@ -1102,6 +1105,14 @@ int pt_hip_render_wavefront_noalloc(const pt_frame* frame, const void* scene_blo
 	return render_wavefront_impl(frame, scene_blob, n_triangles, n_materials, frame_first, mean_first, n_samples, samples_per_pass,
 	                             rng, mean, ws, (size_t)PT_NOALLOC_SCRATCH_BYTES, stats, stream);
 }
+
+#ifdef PT_BVH_COUNT
+int pt_hip_debug_bvh_counts(unsigned long long* out, int reset) {
+	if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_bvh_count), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_bvh_count), z, sizeof(z)) != hipSuccess) return -1; }
+	return 0;
+}
+#endif
 
 int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                         uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,

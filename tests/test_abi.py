@@ -138,7 +138,25 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 32 * n_tris
     assert hdr_f[12] > 0 and hdr_f[13] > 0                       # radius, kappa_root
     # QNode, 32 bytes: 12 uint16 grid coordinates (lo0 hi0 lo1 hi1) + two child words; the grid is bvh_grid(center, radius)
-    assert n == bvh_off + (32 + 64) * n_tris                     # the blob: header, triangles, materials | nodes | leaf records
+    assert n == bvh_off + (32 + 64) * n_tris + 192               # the blob: header, triangles, materials | nodes | leaf records | normal classes
+    # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis, tau}: every triangle's plane lies in one of the cones, and
+    # |cos(axis, normal)| >= cos(half-angle) with tau = sin(half-angle + asin(0.02)) (+ margins) for all of its members
+    cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 192]
+    n_classes, all_classified = int(cb[:8].view(np.uint32)[0]), int(cb[:8].view(np.uint32)[1])
+    cls = cb[16:16 + 16 * 8].view(np.float32).reshape(8, 4).astype(np.float64)
+    assert all_classified == 1 and n_classes == 3                # the faces of an axis-aligned box: three plane directions
+    Pd = np.array(V, dtype=np.float64)[:, :3]
+    Ti = np.array(T, dtype=np.int64)
+    nrm = np.cross(Pd[Ti[:, 1]] - Pd[Ti[:, 0]], Pd[Ti[:, 2]] - Pd[Ti[:, 0]])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    for nv in nrm:
+        ok = False
+        for k in range(n_classes):
+            ax, tau = cls[k, :3], cls[k, 3]
+            cos_h = abs(ax @ nv) / np.linalg.norm(ax)
+            if np.arcsin(min(1.0, tau / np.linalg.norm(ax))) >= np.arccos(min(1.0, cos_h)) + np.arcsin(0.02):
+                ok = True
+        assert ok
     nodes_q = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.uint16).reshape(n_nodes, 16)
     nodes_i = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.int32).reshape(n_nodes, 8)
     half = np.float32(1.0001) * hdr_f[12] + np.float32(1e-6)
