@@ -51,11 +51,12 @@ static_assert(sizeof(Node) == 64, "BVH node is 4 float4");
 // 32 bytes, what the traversal reads: the same node with its boxes on a 16-bit grid over the scene's bounding cube
 // (ptd::bvh_grid), lower corners rounded down, upper corners up, so a quantised box contains the exact one.  The node
 // walk is bound by the number of cache lines a wave's 64 lanes touch per step (every lane is at a different node):
-// two 16-byte loads per lane and step instead of four.  The per-child kappa is gone from the node: every box is
+// two 16-byte loads per lane and step instead of four.  A word holds one axis of one child, {lo, hi}, so that the traversal
+// picks the plane a ray enters through and the one it leaves through with one byte-permute each (pt_device.hpp box_hit).  The per-child kappa is gone from the node: every box is
 // inflated for the scene's largest kappa, which is what the deepest boxes -- most of the tests -- needed anyway.
 struct QNode {
-	uint16_t lo0[3], hi0[3];
-	uint16_t lo1[3], hi1[3];
+	uint16_t box0[3][2];        // child 0: per axis {lo, hi}: one 32-bit word per axis, lo in its low half
+	uint16_t box1[3][2];        // child 1
 	int32_t child0, child1;     // as Node
 };
 static_assert(sizeof(QNode) == 32, "quantised BVH node is 2 x 16 bytes");
@@ -161,8 +162,8 @@ inline std::vector<QNode> quantize(const std::vector<Node>& nodes, const float g
 		const Node& n = nodes[i];
 		QNode& q = out[i];
 		for (int k = 0; k < 3; k++) {
-			q.lo0[k] = grid_down(n.lo0[k], glo[k], cell); q.hi0[k] = grid_up(n.hi0[k], glo[k], cell);
-			q.lo1[k] = grid_down(n.lo1[k], glo[k], cell); q.hi1[k] = grid_up(n.hi1[k], glo[k], cell);
+			q.box0[k][0] = grid_down(n.lo0[k], glo[k], cell); q.box0[k][1] = grid_up(n.hi0[k], glo[k], cell);
+			q.box1[k][0] = grid_down(n.lo1[k], glo[k], cell); q.box1[k][1] = grid_up(n.hi1[k], glo[k], cell);
 		}
 		q.child0 = n.child0; q.child1 = n.child1;
 	}

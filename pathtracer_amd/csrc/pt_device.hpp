@@ -339,18 +339,50 @@ __device__ unsigned long long g_bvh_count[8];
 #define PT_COUNT_WAVE(pred, lanes, trips) ((void)0)
 #endif
 
-// Slab test of one child box in grid units.  ol / oh = the ray origin on the grid plus / minus the inflation, so
-// (l - ol) = (l - infl) - o and (h - oh) = (h + infl) - o; inv = cell / direction; [tlo, thi] is the (widened) ray interval.
-__device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, float hy, float hz,
-                                        Vec3 ol, Vec3 oh, Vec3 inv, float tlo, float thi, float& tnear) {
-	float ax = (lx - ol.x) * inv.x, bx = (hx - oh.x) * inv.x;
-	float ay = (ly - ol.y) * inv.y, by = (hy - oh.y) * inv.y;
-	float az = (lz - ol.z) * inv.z, bz = (hz - oh.z) * inv.z;
-	float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tlo));
-	float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), thi));
+// Slab test of one child box in grid units.  The walk is bound by VALU issue (camera rays: 3.7 cycles per wave64 VALU
+// instruction, and v_cvt / v_min / v_max / v_perm / v_cmp issue at 4.3, v_fma at 2.5: tools/valu_microbench.hip), so the
+// test is cut to what the ray needs.  wx, wy, wz: the child's {lo, hi} grid coordinates of one axis each.  A ray enters a
+// slab through lo or hi depending on the sign of its direction, known per ray: ONE v_perm_b32 per plane both picks the
+// half-word and makes it a float (bytes {0x4B, 0x00, q.hi, q.lo} = 2^23 + q exactly) -- no v_cvt, no min/max per axis --,
+// and one fma per plane takes it to the ray parameter: t = (2^23 + q) * inv + c with c = -(2^23 + o -/+ infl) * inv from
+// the set-up.  The 2^23 costs accuracy: both products are rounded at the magnitude of 2^23 * inv, half a cell's worth
+// each, whatever inv is -- the set-up adds two cells to the inflation for it (1e-4 of the scene's size).
+// [tlo, thi] is the (widened) ray interval.
+__device__ __forceinline__ uint32_t perm_bytes(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(hi_src, lo_src, sel);
+#else
+	// v_perm_b32: byte k of the result is byte sel[k] of {hi_src (4..7), lo_src (0..3)}; 12 = 0x00 (host builds: tests/host)
+	uint32_t r = 0;
+	for (int k = 0; k < 4; k++) {
+		uint32_t c = (sel >> (8 * k)) & 255u;
+		uint32_t b = c < 4u ? (lo_src >> (8 * c)) & 255u : c < 8u ? (hi_src >> (8 * (c - 4u))) & 255u : c == 12u ? 0u : 255u;
+		r |= b << (8 * k);
+	}
+	return r;
+#endif
+}
+constexpr uint32_t kPermBias = 0x4B000000u;          // 2^23 as a float: its top two bytes head every decoded coordinate
+constexpr uint32_t kPermLo = 0x07060100u;            // {bias.b3, bias.b2, w.b1, w.b0}: the low half-word  (lo)
+constexpr uint32_t kPermHi = 0x07060302u;            // {bias.b3, bias.b2, w.b3, w.b2}: the high half-word (hi)
+
+struct BvhRay {              // per-ray constants of the box tests
+	Vec3 inv;                // cell / direction: grid distance -> ray parameter
+	Vec3 cn, cf;             // -(2^23 + origin on the grid -/+ inflation) * inv for the plane the ray enters / leaves through
+	uint32_t snx, sny, snz;  // v_perm selectors of the entry plane per axis (kPermLo for a positive direction); exit: ^ kPermFlip
+	float dt;                // widening of the ray interval: [-dt, best_t + dt]
+};
+constexpr uint32_t kPermFlip = kPermLo ^ kPermHi;
+
+__device__ __forceinline__ bool box_hit(uint32_t wx, uint32_t wy, uint32_t wz, const BvhRay& r, float thi, float& tnear) {
+	float nx = __uint_as_float(perm_bytes(kPermBias, wx, r.snx)), fx = __uint_as_float(perm_bytes(kPermBias, wx, r.snx ^ kPermFlip));
+	float ny = __uint_as_float(perm_bytes(kPermBias, wy, r.sny)), fy = __uint_as_float(perm_bytes(kPermBias, wy, r.sny ^ kPermFlip));
+	float nz = __uint_as_float(perm_bytes(kPermBias, wz, r.snz)), fz = __uint_as_float(perm_bytes(kPermBias, wz, r.snz ^ kPermFlip));
+	float t0 = fmaxf(fmaxf(__builtin_fmaf(nx, r.inv.x, r.cn.x), __builtin_fmaf(ny, r.inv.y, r.cn.y)), fmaxf(__builtin_fmaf(nz, r.inv.z, r.cn.z), -r.dt));
+	float t1 = fminf(fminf(__builtin_fmaf(fx, r.inv.x, r.cf.x), __builtin_fmaf(fy, r.inv.y, r.cf.y)), fminf(__builtin_fmaf(fz, r.inv.z, r.cf.z), thi));
 	tnear = t0;
-	// widen by a relative hair for the products' own rounding (the absolute part is in the inflation)
-	return t0 <= t1 + 1e-5f * fabsf(t1);
+	// widen by a relative hair for the fma's own rounding (the absolute part is in the inflation)
+	return t0 <= __builtin_fmaf(fabsf(t1), 1e-5f, t1);
 }
 
 __device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint32_t code, bool det_bounded, Vec3 o, Vec3 d,
@@ -393,12 +425,6 @@ constexpr int kBvhQuorum = PT_BVH_QUORUM;
 #define PT_BVH_RATIO 4
 #endif
 
-struct BvhRay {              // per-ray constants of the box tests
-	Vec3 inv;                // cell / direction: grid distance -> ray parameter
-	Vec3 ol, oh;             // origin on the grid + / - the inflation of every box (grid units)
-	float dt, tlo;
-};
-
 __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 d, float best_t) {
 	// a zero component would make 0 * inf = NaN in the slabs; a direction error of 1e-20 is far inside the inflation
 	Vec3 dd{ fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x, fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y,
@@ -412,7 +438,6 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
 	float delta_root = bv.kappa_root * s_ray + bv.slack;     // how far outside its triangle an accepted hit can be
 	r.dt = 1.01f * delta_root / dlen;                        // ... in ray-parameter units (the worst case for every ray: it only widens [tlo, thi])
-	r.tlo = -r.dt;
 	// A "calm" ray -- at least asin(kRho) away from grazing every triangle of the scene (pt_bvh.hpp, normal classes) -- needs
 	// only the size-independent inflation for the boxes.  dhat to ~1e-6 (v_rcp): tau carries 1e-4 relative + 1e-5 for it.
 	bool calm = bv.n_classes != 0u;
@@ -429,9 +454,17 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	// value that can reach 65535 + the camera's distance) and that of the slab's (q - o) go into the inflation, four
 	// times over: 1e-6 of the magnitudes involved -- hundredths of a cell, against boxes tens of cells wide.
 	Vec3 og{ (o.x - bv.glo.x) * bv.inv_cell, (o.y - bv.glo.y) * bv.inv_cell, (o.z - bv.glo.z) * bv.inv_cell };
-	float infl = 1.00001f * (delta_box * bv.inv_cell) + 1e-6f * (65536.0f + fabsf(og.x) + fabsf(og.y) + fabsf(og.z));
-	r.ol = Vec3{ og.x + infl, og.y + infl, og.z + infl };
-	r.oh = Vec3{ og.x - infl, og.y - infl, og.z - infl };
+	// (+ 2 cells: the 2^23 bias of box_hit's decoded coordinates, see there)
+	float infl = 1.00001f * (delta_box * bv.inv_cell) + 1e-6f * (65536.0f + fabsf(og.x) + fabsf(og.y) + fabsf(og.z)) + 2.0f;
+	// a ray with a positive direction component enters through lo - infl and leaves through hi + infl; a negative one the
+	// other way round.  c = -(2^23 + plane offset) * inv, the 2^23 apart so that the origin keeps its fraction of a cell.
+	const float bias = 8388608.0f;
+	bool px = dd.x >= 0.0f, py = dd.y >= 0.0f, pz = dd.z >= 0.0f;
+	r.snx = px ? kPermLo : kPermHi; r.sny = py ? kPermLo : kPermHi; r.snz = pz ? kPermLo : kPermHi;
+	// entry plane p = (positive ? lo - infl : hi + infl): t = (p - og) * inv = q * inv - (og + e) * inv, e = +/-infl; exit: - e
+	float ex = px ? infl : -infl, ey = py ? infl : -infl, ez = pz ? infl : -infl;
+	r.cn = Vec3{ -(og.x + ex) * r.inv.x - bias * r.inv.x, -(og.y + ey) * r.inv.y - bias * r.inv.y, -(og.z + ez) * r.inv.z - bias * r.inv.z };
+	r.cf = Vec3{ -(og.x - ex) * r.inv.x - bias * r.inv.x, -(og.y - ey) * r.inv.y - bias * r.inv.y, -(og.z - ez) * r.inv.z - bias * r.inv.z };
 	return r;
 }
 
@@ -473,11 +506,9 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 			int32_t c0 = (int32_t)w1.z, c1 = (int32_t)w1.w;
 			float thi = best_t + r.dt + 1e-6f * best_t;
 			float tn0, tn1;
-			// QNode: 12 grid coordinates, two to a word (exact as floats)
-			bool h0 = box_hit((float)(w0.x & 0xFFFFu), (float)(w0.x >> 16), (float)(w0.y & 0xFFFFu),
-			                  (float)(w0.y >> 16), (float)(w0.z & 0xFFFFu), (float)(w0.z >> 16), r.ol, r.oh, r.inv, r.tlo, thi, tn0);
-			bool h1 = box_hit((float)(w0.w & 0xFFFFu), (float)(w0.w >> 16), (float)(w1.x & 0xFFFFu),
-			                  (float)(w1.x >> 16), (float)(w1.y & 0xFFFFu), (float)(w1.y >> 16), r.ol, r.oh, r.inv, r.tlo, thi, tn1);
+			// QNode: a word per child and axis, {lo, hi}
+			bool h0 = box_hit(w0.x, w0.y, w0.z, r, thi, tn0);
+			bool h1 = box_hit(w0.w, w1.x, w1.y, r, thi, tn1);
 			if (h0 && h1) {
 				bool first0 = tn0 <= tn1;
 				if (sp < bv.stack_depth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }     // never false: see bvh_stack_depth

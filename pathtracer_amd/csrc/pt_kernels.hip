@@ -225,7 +225,7 @@ __global__ void k_set_count(uint32_t* __restrict__ counts, uint32_t G, uint32_t 
 
 // a5+a6. Scene triangles staged in LDS; one thread per queue entry, block-uniform loops.
 template <bool FIRST, bool BVH>
-__global__ __launch_bounds__(kBlock) void k_extend(float4 origin, float4 camera, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
+__global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 camera, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                    const float4* __restrict__ qa, const float4* __restrict__ qb,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t capacity,
                                                    uint2* __restrict__ hit) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_f32(float* __restrict__ dst, fl
 // (tried and dropped: the reference's 4 triangles held in SGPRs across the pixel loop with the triangle loop
 // unrolled -- 22 SGPR spills, 169 vs 174 Grays/s)
 template <bool STRIDED, int SCENE>
-__global__ __launch_bounds__(kBlock, SCENE == 2 ? 1 : 8) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
+__global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
                                                   uint32_t mean_first, uint32_t n_samples,
                                                   uint32_t* __restrict__ rng_io, float4* __restrict__ mean_io,

@@ -137,7 +137,7 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     n_tris, n_nodes, bvh_off, leaf_off = int(hdr_u[0]), int(hdr_u[6]), int(hdr_u[7]), int(hdr_u[8])
     assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 32 * n_tris
     assert hdr_f[12] > 0 and hdr_f[13] > 0                       # radius, kappa_root
-    # QNode, 32 bytes: 12 uint16 grid coordinates (lo0 hi0 lo1 hi1) + two child words; the grid is bvh_grid(center, radius)
+    # QNode, 32 bytes: 12 uint16 grid coordinates -- per child and axis {lo, hi} -- + two child words; the grid is bvh_grid(center, radius)
     assert n == bvh_off + (32 + 64) * n_tris + 192               # the blob: header, triangles, materials | nodes | leaf records | normal classes
     # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis, tau}: every triangle's plane lies in one of the cones, and
     # |cos(axis, normal)| >= cos(half-angle) with tau = sin(half-angle + asin(0.02)) (+ margins) for all of its members
@@ -188,7 +188,7 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
                 assert kappa_root >= 16 * 2.0**-24 / 1e-6 * np.linalg.norm(e0) * np.linalg.norm(e1) * (1 - 1e-5)
             return
         q, ni = nodes_q[child].astype(np.float64), nodes_i[child]
-        lo0, hi0, lo1, hi1 = glo + q[0:3] * cell, glo + q[3:6] * cell, glo + q[6:9] * cell, glo + q[9:12] * cell
+        lo0, hi0, lo1, hi1 = glo + q[0:6:2] * cell, glo + q[1:6:2] * cell, glo + q[6:12:2] * cell, glo + q[7:12:2] * cell
         assert (lo0 >= lo).all() and (hi0 <= hi).all() and (lo1 >= lo).all() and (hi1 <= hi).all()
         # outward rounding costs at most one cell per face
         deepest[0] = max(deepest[0], depth)

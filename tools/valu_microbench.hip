@@ -50,6 +50,13 @@ BENCH_KERNEL(k_mul_lo, "v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mu
 BENCH_KERNEL(k_div_fixup, "v_div_fixup_f32 %0, %0, %4, %5\n v_div_fixup_f32 %1, %1, %4, %5\n v_div_fixup_f32 %2, %2, %5, %4\n v_div_fixup_f32 %3, %3, %5, %4\n")
 BENCH_KERNEL(k_div_fmas, "v_div_fmas_f32 %0, %0, %4, %5\n v_div_fmas_f32 %1, %1, %4, %5\n v_div_fmas_f32 %2, %2, %5, %4\n v_div_fmas_f32 %3, %3, %5, %4\n")
 BENCH_KERNEL(k_div_scale, "v_div_scale_f32 %0, vcc, %0, %4, %5\n v_div_scale_f32 %1, vcc, %1, %4, %5\n v_div_scale_f32 %2, vcc, %2, %5, %4\n v_div_scale_f32 %3, vcc, %3, %5, %4\n")
+BENCH_KERNEL(k_perm, "v_perm_b32 %0, %4, %0, %5\n v_perm_b32 %1, %4, %1, %5\n v_perm_b32 %2, %5, %2, %4\n v_perm_b32 %3, %5, %3, %4\n")
+BENCH_KERNEL(k_max3, "v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %5, %4\n v_max3_f32 %3, %3, %5, %4\n")
+BENCH_KERNEL(k_and_or, "v_and_or_b32 %0, %0, %4, %5\n v_and_or_b32 %1, %1, %4, %5\n v_and_or_b32 %2, %2, %5, %4\n v_and_or_b32 %3, %3, %5, %4\n")
+BENCH_KERNEL(k_cvt_sdwa, "v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n")
+BENCH_KERNEL(k_fma_abs, "v_fma_f32 %0, |%0|, %4, %5\n v_fma_f32 %1, |%1|, %4, %5\n v_fma_f32 %2, |%2|, %5, %4\n v_fma_f32 %3, |%3|, %5, %4\n")
+BENCH_KERNEL(k_cvt_ubyte, "v_cvt_f32_ubyte1 %0, %0\n v_cvt_f32_ubyte2 %1, %1\n v_cvt_f32_ubyte0 %2, %2\n v_cvt_f32_ubyte3 %3, %3\n")
+BENCH_KERNEL(k_alignbit, "v_alignbit_b32 %0, %0, %4, 16\n v_alignbit_b32 %1, %1, %4, 16\n v_alignbit_b32 %2, %2, %5, 16\n v_alignbit_b32 %3, %3, %5, 16\n")
 BENCH_KERNEL(k_mov, "v_mov_b32 %0, %4\n v_mov_b32 %1, %5\n v_mov_b32 %2, %4\n v_mov_b32 %3, %5\n")
 
 // packed: 2 floats per operand
@@ -114,6 +121,8 @@ int main() {
 		{ "v_cmp_lt_u32", k_cmp_u32 }, { "v_cmp_lt_f32_e64 sgpr", k_cmp_e64 }, { "v_mul_f32 sgpr operand", k_mul_sgpr }, { "v_rsq_f32", k_rsq }, { "v_cmp_lt_f32", k_cmp },
 		{ "v_cvt_f32_u32", k_cvt }, { "v_rcp_f32", k_rcp }, { "v_sqrt_f32", k_sqrt }, { "v_mul_lo_u32", k_mul_lo },
 		{ "v_div_scale_f32", k_div_scale }, { "v_div_fmas_f32", k_div_fmas }, { "v_div_fixup_f32", k_div_fixup },
+		{ "v_perm_b32", k_perm }, { "v_max3_f32", k_max3 }, { "v_and_or_b32", k_and_or }, { "v_cvt_f32_u32_sdwa", k_cvt_sdwa }, { "v_fma_f32 |src|", k_fma_abs },
+		{ "v_cvt_f32_ubyteN", k_cvt_ubyte }, { "v_alignbit_b32", k_alignbit },
 		{ "v_pk_mul_f32", k_pk_mul }, { "v_pk_add_f32", k_pk_add }, { "v_mul_f32 dependent chain", k_mul_dep },
 	};
 	const int iters = 2000;
