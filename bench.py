@@ -225,6 +225,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries the ONE JSON line and nothing else: what the library prints there (the reference's console messages,
+    # IPathTracerManagement.h / PathTracer.cu) goes to stderr for the length of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+
     import numpy as np
     import torch
     import pathtracer_amd as pt
@@ -296,7 +306,7 @@ def main():
         else:
             tracer.Destroy()
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
 
     # ---------------------------------------------------------------------- sample split over `world` ranks
@@ -419,7 +429,7 @@ def main():
             "kernel_ms_per_step": round(kernel_ms, 4),
             "roofline": roof, "cpu_baseline": None,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     tracer.Destroy()
     dist.barrier()
     dist.destroy_process_group()

@@ -1,19 +1,22 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence DESIGN.md quotes: kernel-trace stats of the default bench command and of the
-# wavefront engine, then HBM-traffic and SQ counters in separate --pmc passes (never combined with tracing).
-# Usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
-set -e
-TAG=${1:-r01}
+# One GPU-box call that produces what a round commits under profiles/: GPU tests, the bench line, rocprofv3 kernel-trace
+# summaries of the bench (default workload, both engines; C4-10k wavefront) and the PMC passes bench.py's roofline is priced with.
+# Usage (GPU box, repo root): bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
+# Every GPU step has its own time limit and the script stops at the first step that fails.
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fused -- python bench.py > $OUT/bench_fused.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wave -- python bench.py --engine wavefront --cpu-spp 0 > $OUT/bench_wave.log 2>&1
-B="python bench.py --steps 5 --warmup 1 --cpu-spp 0"
-for eng in fused wavefront; do
-  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_LDS" "GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU"; do
-    n=$(echo $c | cut -d" " -f1)
-    timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${eng}_$n -- $B --engine $eng > $OUT/pmc_${eng}_$n.log 2>&1
-  done
+set -e
+if [ "${SKIP_TESTS:-0}" != 1 ]; then
+  timeout -k 10 600 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $OUT/pytest_gpu.log 2>&1 || { tail -30 $OUT/pytest_gpu.log; exit 1; }
+  tail -2 $OUT/pytest_gpu.log
+fi
+timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+echo bench_done
+for spec in "default fused" "default wavefront" "c4_10k wavefront" "c5 wavefront"; do
+  set -- $spec
+  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$1_$2 -- python3 bench.py --bare --workload $1 --engine $2 --steps 10 --warmup 2 > $OUT/kt_$1_$2.log 2>&1 || { echo "kernel trace $1 $2 failed"; tail -5 $OUT/kt_$1_$2.log; exit 1; }
+  echo "kernel trace $1 $2 done"
 done
-echo profile_done
+bash tools/measure_counters.sh $TAG
