@@ -330,13 +330,34 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	return v;
 }
 
-#ifdef PT_BVH_COUNT
-// debug build only (tools/bvh_counts.py): lane- and wave-level work counters of the traversal
+#if defined(PT_BVH_COUNT) || defined(PT_BVH_TIME)
+// debug builds only (tools/bvh_counts.py): work counters of the traversal (-DPT_BVH_COUNT: lane- and wave-level trips, two
+// atomics per trip, so that build's timings mean nothing) or the cycles a wave spends in each phase (-DPT_BVH_TIME)
 __device__ unsigned long long g_bvh_count[8];
 #define PT_COUNT(i, v) atomicAdd(&g_bvh_count[i], (unsigned long long)(v))
+#endif
+#ifdef PT_BVH_COUNT
 #define PT_COUNT_WAVE(pred, lanes, trips) do { unsigned long long w_ = __ballot(pred); if (w_ && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(w_)) { PT_COUNT(lanes, __popcll(w_)); PT_COUNT(trips, 1); } } while (0)
 #else
 #define PT_COUNT_WAVE(pred, lanes, trips) ((void)0)
+#endif
+#ifdef PT_BVH_TIME
+// cycles of phase i (4 node walk, 5 leaf tests, 6 write-back + refill), summed in registers (t_acc[i - 4]); one add per wave at the end
+#define PT_TIME_DECL() long long t_acc[3] = { 0, 0, 0 }
+#define PT_TIME_ARG , t_acc
+#define PT_TIME_PARAM , long long* t_acc
+#define PT_TIME_NULL() long long* t_acc = nullptr
+#define PT_TIME_BEGIN() long long t_begin_ = clock64()
+#define PT_TIME_END(i) do { if (t_acc) t_acc[(i) - 4] += clock64() - t_begin_; } while (0)
+#define PT_TIME_FLUSH() do { if ((threadIdx.x & 63u) == 0u) for (int k_ = 0; k_ < 3; k_++) PT_COUNT(4 + k_, t_acc[k_]); } while (0)
+#else
+#define PT_TIME_DECL() ((void)0)
+#define PT_TIME_ARG
+#define PT_TIME_PARAM
+#define PT_TIME_NULL() ((void)0)
+#define PT_TIME_BEGIN() ((void)0)
+#define PT_TIME_END(i) ((void)0)
+#define PT_TIME_FLUSH() ((void)0)
 #endif
 
 // Slab test of one child box in grid units.  The walk is bound by VALU issue (camera rays: 3.7 cycles per wave64 VALU
@@ -482,9 +503,10 @@ __device__ __forceinline__ int32_t bvh_pop(uint32_t* stack, int& sp) {
 // one -- tried, and slower (see the define).  The order in which leaves are tested cannot
 // change the result: bvh_leaf ranks hits by (t, original index).
 __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
-                                          int32_t& cur, int& sp, uint32_t* stack) {
+                                          int32_t& cur, int& sp, uint32_t* stack PT_TIME_PARAM) {
 	constexpr int32_t kNone = 0;                       // node 0 is the root and never a child, so 0 is free as "no parked leaf"
 	int32_t pend = kNone;
+	PT_TIME_BEGIN();
 	for (;;) {
 		if (kBvhQuorum > 0) {
 			// (every lane of the calling context reaches these ballots: lanes that stand on a leaf stay in the loop, idle)
@@ -521,10 +543,15 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 			cur = bvh_pop(stack, sp);
 		} else if (kBvhQuorum == 0) break;
 	}
-	if (pend != kNone) bvh_leaf(bv.leaves, (uint32_t)~pend, bv.det_bounded, o, d, best_t, hit_tri);
-	if (cur < 0) {
-		bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
-		cur = bvh_pop(stack, sp);
+	PT_TIME_END(4);
+	{
+		PT_TIME_BEGIN();
+		if (pend != kNone) bvh_leaf(bv.leaves, (uint32_t)~pend, bv.det_bounded, o, d, best_t, hit_tri);
+		if (cur < 0) {
+			bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
+			cur = bvh_pop(stack, sp);
+		}
+		PT_TIME_END(5);
 	}
 }
 
@@ -533,7 +560,8 @@ __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d,
 	BvhRay r = bvh_ray_setup(bv, o, d, best_t);
 	int32_t cur = 0;
 	int sp = 0;
-	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack);
+	PT_TIME_NULL();
+	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack PT_TIME_ARG);
 }
 
 #ifndef PT_BVH_REFILL
@@ -561,7 +589,9 @@ __device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origi
 	int32_t cur = kBvhDone;
 	int sp = 0;
 	bool has_ray = false, exhausted = false;
+	PT_TIME_DECL();
 	for (;;) {
+		PT_TIME_BEGIN();
 		bool idle = cur == kBvhDone;
 		if (idle && has_ray) { hit[q] = uint2{ __float_as_uint(best), tri }; has_ray = false; }
 		unsigned long long idle_mask = __ballot(idle);
@@ -589,9 +619,11 @@ __device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origi
 				}
 			}
 		}
+		PT_TIME_END(6);
 		if (!__any(cur != kBvhDone)) { if (exhausted) break; else continue; }
-		bvh_round(bv, r, o, d, best, tri, cur, sp, stack);
+		bvh_round(bv, r, o, d, best, tri, cur, sp, stack PT_TIME_ARG);
 	}
+	PT_TIME_FLUSH();
 }
 
 // GetDiffuseReflection, Functions.cuh:91-109: rounds of 3 draws (x, y, z in that order) until

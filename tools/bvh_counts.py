@@ -27,4 +27,5 @@ for depth in (1, 10):
     rays = st.rays
     print(f"triangles {len(T)} depth {depth}: rays {rays}  node steps/ray {out[0] / rays:.1f}  node trips per wave-of-64-rays {out[1] / (rays / 64):.1f} "
           f"(lanes busy {out[0] / max(1, out[1]):.1f})  triangle tests/ray {out[2] / rays:.1f}  triangle trips per 64 rays {out[3] / (rays / 64):.1f} "
-          f"(lanes busy {out[2] / max(1, out[3]):.1f})")
+          f"(lanes busy {out[2] / max(1, out[3]):.1f})  wave cycles per 64 rays: node walk {out[4] / (rays / 64):.0f}, leaf tests {out[5] / (rays / 64):.0f}, "
+          f"write-back + refill {out[6] / (rays / 64):.0f}")
