@@ -301,6 +301,7 @@ struct BvhView {
 	int stack_depth;         // bvh_stack_depth(n_tris)
 	const float4* classes;   // pt_bvh.hpp NormalClass {axis, tau} x n_classes (wave-uniform reads)
 	uint32_t n_classes;      // 0: no ray is ever "calm" (slivers, or more plane directions than classes)
+	uint32_t n_nodes, n_tris; // sizes of `nodes` and `leaves` (read by the -DPT_BVH_CHECK build only)
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -324,13 +325,15 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	v.max_edge = hdr->max_edge;
 	v.det_bounded = (hdr->flags & kSceneDetBounded) != 0;
 	v.stack_depth = (int)bvh_stack_depth(n_tris);
+	v.n_nodes = hdr->n_nodes;
+	v.n_tris = n_tris;
 	const uint32_t* cb = reinterpret_cast<const uint32_t*>(scene + off + (size_t)n_tris * (kBvhNodeBytes + 64u));
 	v.n_classes = cb[1] != 0u ? (cb[0] < kBvhMaxClasses ? cb[0] : kBvhMaxClasses) : 0u;      // {n_classes, all_classified, ..}
 	v.classes = reinterpret_cast<const float4*>(cb + 4);
 	return v;
 }
 
-#if defined(PT_BVH_COUNT) || defined(PT_BVH_TIME)
+#if defined(PT_BVH_COUNT) || defined(PT_BVH_TIME) || defined(PT_BVH_CHECK)
 // debug builds only (tools/bvh_counts.py): work counters of the traversal (-DPT_BVH_COUNT: lane- and wave-level trips, two
 // atomics per trip, so that build's timings mean nothing) or the cycles a wave spends in each phase (-DPT_BVH_TIME)
 __device__ unsigned long long g_bvh_count[8];
@@ -340,6 +343,14 @@ __device__ unsigned long long g_bvh_count[8];
 #define PT_COUNT_WAVE(pred, lanes, trips) do { unsigned long long w_ = __ballot(pred); if (w_ && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(w_)) { PT_COUNT(lanes, __popcll(w_)); PT_COUNT(trips, 1); } } while (0)
 #else
 #define PT_COUNT_WAVE(pred, lanes, trips) ((void)0)
+#endif
+#ifdef PT_BVH_CHECK
+// -DPT_BVH_CHECK (tools/bvh_range_check.py): every index the traversal is about to use -- node, leaf record, stack level --
+// is compared with the size of its array; a violation is counted in g_bvh_count[7] and the access skipped (the ray is
+// dropped), so the build never faults and one run shows whether the shipped sizing holds.
+#define PT_CHECK(cond, bail) do { if (!(cond)) { PT_COUNT(7, 1); bail; } } while (0)
+#else
+#define PT_CHECK(cond, bail) ((void)0)
 #endif
 #ifdef PT_BVH_TIME
 // cycles of phase i (4 node walk, 5 leaf tests, 6 write-back + refill), summed in registers (t_acc[i - 4]); one add per wave at the end
@@ -517,6 +528,7 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 		}
 		PT_COUNT_WAVE((uint32_t)cur < (uint32_t)kBvhDone, 0, 1);
 		if ((uint32_t)cur < (uint32_t)kBvhDone) {
+			PT_CHECK((uint32_t)cur < bv.n_nodes && sp >= 0 && sp <= bv.stack_depth, { cur = kBvhDone; sp = 0; continue; });
 			const uint4* n = bv.nodes + (size_t)cur * 2;
 			uint4 w0 = n[0], w1 = n[1];
 #ifdef PT_EXP_EXTRA_LOAD
@@ -533,6 +545,7 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 			bool h1 = box_hit(w0.w, w1.x, w1.y, r, thi, tn1);
 			if (h0 && h1) {
 				bool first0 = tn0 <= tn1;
+				PT_CHECK(sp < bv.stack_depth, {});
 				if (sp < bv.stack_depth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }     // never false: see bvh_stack_depth
 				cur = first0 ? c0 : c1;
 			} else if (h0) cur = c0;
@@ -548,6 +561,7 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 		PT_TIME_BEGIN();
 		if (pend != kNone) bvh_leaf(bv.leaves, (uint32_t)~pend, bv.det_bounded, o, d, best_t, hit_tri);
 		if (cur < 0) {
+			PT_CHECK(((uint32_t)~cur >> 3) + ((uint32_t)~cur & 7u) < bv.n_tris && sp >= 0 && sp <= bv.stack_depth, { cur = kBvhDone; sp = 0; return; });
 			bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
 			cur = bvh_pop(stack, sp);
 		}
