@@ -134,6 +134,17 @@ void* pt_stream(pt_handle* h);
 void* pt_device_mean(pt_handle* h);
 int pt_get_stats(pt_handle* h, pt_stats* out);
 
+/* Checkpoint / resume (no reference counterpart: PathTracer.cu keeps its accumulation only in the GL
+ * texture and loses it on exit).  pt_save_state writes options, camera, the sample count, every pixel's RNG stream, the
+ * running mean(s) and the counters to `path` (atomically: a temporary file, then rename); pt_load_state on an instance of
+ * the same image size holding the same scene applies the file's options and continues the accumulation bit for bit, as if
+ * the run had never stopped.  PT_ERR_STATE: other size or scene, or a camera change pending at save time. */
+int pt_save_state(pt_handle* h, const char* path);
+int pt_load_state(pt_handle* h, const char* path);
+/* The camera the instance renders with (the last Update, or the one a state file brought): a host that resumes hands this
+ * to its next Update so that it does not restart the accumulation (PathTracer.cu:99-101). */
+int pt_get_camera(pt_handle* h, pt_camera_data* out);
+
 /* ---- sample split: combining the shards (PT_SPLIT_SAMPLE).  After a combine, pt_readback / pt_copy_mean of the instance
  * that holds the result return the IMAGE (pixel_count float4); pt_device_mean stays the instance's own shard means
  * (local shards x pitch float4, see pt_get_shard_layout).  A single instance (split_ranks <= 1) combines by itself on

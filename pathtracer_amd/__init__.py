@@ -115,6 +115,9 @@ SYMBOLS = {
     "pt_scene_file_free": (None, [_VP]),
     "pt_scene_file_write": (C.c_int, [C.c_char_p, _VP, _U32, _VP, _U32, _VP, _U32]),
     "pt_load_scene": (C.c_int, [_VP, C.c_char_p]),
+    "pt_save_state": (C.c_int, [_VP, C.c_char_p]),
+    "pt_load_state": (C.c_int, [_VP, C.c_char_p]),
+    "pt_get_camera": (C.c_int, [_VP, C.POINTER(CameraData)]),
     "pt_render": (C.c_int, [_VP, _U32]),
     "pt_readback": (C.c_int, [_VP, _VP, _SZ]),
     "pt_readback_rng": (C.c_int, [_VP, _VP, _SZ]),
@@ -319,6 +322,19 @@ class PathTracer:
 
     def load_scene(self, path: str) -> None:
         _check(self._lib.pt_load_scene(self._h, os.fsencode(path)), self._lib, "pt_load_scene")
+
+    def save_state(self, path: str) -> None:
+        """checkpoint: options, camera, sample count, RNG streams, running mean(s), counters (include/pt_plugin.h)"""
+        _check(self._lib.pt_save_state(self._h, os.fsencode(path)), self._lib, "pt_save_state")
+
+    def camera(self) -> CameraData:
+        cam = CameraData()
+        _check(self._lib.pt_get_camera(self._h, C.byref(cam)), self._lib, "pt_get_camera")
+        return cam
+
+    def load_state(self, path: str) -> None:
+        """resume a checkpoint on an instance of the same size and scene: the accumulation continues bit for bit"""
+        _check(self._lib.pt_load_state(self._h, os.fsencode(path)), self._lib, "pt_load_state")
 
     def render(self, spp: int) -> None:
         _check(self._lib.pt_render(self._h, int(spp)), self._lib, "pt_render")

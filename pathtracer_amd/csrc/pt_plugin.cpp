@@ -99,6 +99,7 @@ class PathTracer final : public IPathTracer {
 	size_t _workspaceBytes = 0, _stackedBytes = 0;
 	uint32_t _nTris = 0, _nMats = 0;
 	bool _sceneHasBvh = false;          // recorded when the scene is packed (pt_hip_scene_has_bvh), passed with every frame
+	uint64_t _sceneHash = 0;            // FNV-1a of the packed blob: a state file is only resumed on the scene it was saved on
 	int _device = -1;                   // resolved HIP ordinal of this instance, bound by every method (DeviceScope)
 	void* _stream = nullptr;
 	void* _evStart = nullptr;
@@ -294,6 +295,8 @@ public:
 		PT_TRY(pt_hip_stream_synchronize(_stream));
 		pt_hip_free(_dev.scene);
 		_dev.scene = fresh; _nTris = nt; _nMats = nm; _sceneHasBvh = has_bvh != 0;
+		_sceneHash = 1469598103934665603ull;
+		for (unsigned char c : blob) _sceneHash = (_sceneHash ^ c) * 1099511628211ull;
 		_autoPhase = ProbeFused;
 		return _error = _InitializeRendering();
 	}
@@ -360,6 +363,7 @@ public:
 	void* Stream() const { return _stream; }
 	void* DeviceMean() { if (_drawState == Drawing) FinalizeDrawing(); return _dev.mean; }
 	int Device() const { return _device; }
+	const CameraData& CameraState() const { return _camera.Data(); }
 	void ShardLayout(uint32_t* local, uint32_t* pitch, uint32_t* v) const {
 		if (local) *local = _localShards;
 		if (pitch) *pitch = _pitch;
@@ -386,6 +390,82 @@ public:
 		if (h) *h = _height;
 		if (first) *first = _pixelFirst;
 		if (count) *count = _pixelCount;
+	}
+
+	// ---- checkpoint / resume (no reference counterpart: the reference loses its mean when it exits) ----
+	// The file holds what an uninterrupted run would have in memory at this point: options, camera, the number of samples
+	// folded so far, every pixel's RNG stream and the running mean(s), the device counters.  Resuming on the same scene and
+	// image size continues bit for bit (tests/test_checkpoint.py).
+	struct StateHeader {
+		char magic[8];                  // "PTSTATE1"
+		uint32_t header_bytes, width, height, pixel_first, pixel_count, frame_number, local_shards, pitch, n_tris, n_mats;
+		uint64_t scene_hash;
+		pt_options options;
+		CameraData camera;
+		uint32_t _pad;
+		uint64_t stats[PT_STATS_PUBLIC_WORDS];
+		double total_ms;
+		uint64_t renders;
+	};
+	int SaveState(const char* path) {
+		if (_error) return _error;
+		if (!path) return plugin_fail(PT_ERR_INVALID, "save_state: null path");
+		DeviceScope bind(_device);
+		if (_drawState == Drawing) FinalizeDrawing();
+		if (_shouldRestartRendering) return plugin_fail(PT_ERR_STATE, "save_state: the camera changed since the last frame; there is nothing to resume");
+		StateHeader hd{};
+		std::memcpy(hd.magic, "PTSTATE1", 8);
+		hd.header_bytes = (uint32_t)sizeof(StateHeader);
+		hd.width = (uint32_t)_width; hd.height = (uint32_t)_height; hd.pixel_first = _pixelFirst; hd.pixel_count = _pixelCount;
+		hd.frame_number = _frameNumber; hd.local_shards = _localShards; hd.pitch = _pitch; hd.n_tris = _nTris; hd.n_mats = _nMats;
+		hd.scene_hash = _sceneHash; hd.options = _opt; hd.camera = _camera.Data();
+		hd.total_ms = _totalMs; hd.renders = _renders;
+		PT_TRY(pt_hip_memcpy_d2h(hd.stats, _dev.stats, sizeof(hd.stats), _stream));
+		std::vector<uint32_t> rng(_pixelCount);
+		std::vector<float> mean((size_t)_pitch * _localShards * 4);
+		PT_TRY(pt_hip_memcpy_d2h(rng.data(), _dev.rng, rng.size() * sizeof(uint32_t), _stream));
+		PT_TRY(pt_hip_memcpy_d2h(mean.data(), _dev.mean, mean.size() * sizeof(float), _stream));
+		std::string tmp = std::string(path) + ".tmp";
+		FILE* f = std::fopen(tmp.c_str(), "wb");
+		if (!f) return plugin_fail(PT_ERR_INVALID, "save_state: cannot open " + tmp);
+		bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1 && std::fwrite(rng.data(), sizeof(uint32_t), rng.size(), f) == rng.size() &&
+		          std::fwrite(mean.data(), sizeof(float), mean.size(), f) == mean.size();
+		ok = (std::fclose(f) == 0) && ok;
+		if (!ok || std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return plugin_fail(PT_ERR_INVALID, std::string("save_state: cannot write ") + path); }
+		return PT_OK;
+	}
+	int LoadState(const char* path) {
+		if (_error) return _error;
+		if (!path) return plugin_fail(PT_ERR_INVALID, "load_state: null path");
+		FILE* f = std::fopen(path, "rb");
+		if (!f) return plugin_fail(PT_ERR_INVALID, std::string("load_state: cannot open ") + path);
+		struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{ f };
+		StateHeader hd{};
+		if (std::fread(&hd, sizeof(hd), 1, f) != 1 || std::memcmp(hd.magic, "PTSTATE1", 8) != 0 || hd.header_bytes != sizeof(StateHeader))
+			return plugin_fail(PT_ERR_INVALID, "load_state: not a state file of this library version");
+		if ((int)hd.width != _width || (int)hd.height != _height) return plugin_fail(PT_ERR_STATE, "load_state: the state was saved at " + std::to_string(hd.width) + "x" + std::to_string(hd.height) + " (Resize first)");
+		if (hd.scene_hash != _sceneHash || hd.n_tris != _nTris || hd.n_mats != _nMats) return plugin_fail(PT_ERR_STATE, "load_state: the state was saved on another scene (pt_set_scene first)");
+		DeviceScope bind(_device);
+		pt_options o = hd.options;
+		o.device = _opt.device;                      // the device is this instance's, whatever the saving one ran on
+		if (int rc = SetOptions(o)) return rc;       // validates, sizes the buffers, restarts
+		if (hd.pixel_first != _pixelFirst || hd.pixel_count != _pixelCount || hd.local_shards != _localShards || hd.pitch != _pitch)
+			return plugin_fail(PT_ERR_INVALID, "load_state: the file's layout does not follow from its options");
+		std::vector<uint32_t> rng(_pixelCount);
+		std::vector<float> mean((size_t)_pitch * _localShards * 4);
+		if (std::fread(rng.data(), sizeof(uint32_t), rng.size(), f) != rng.size() || std::fread(mean.data(), sizeof(float), mean.size(), f) != mean.size() ||
+		    std::fgetc(f) != EOF)
+			return plugin_fail(PT_ERR_INVALID, "load_state: the file is truncated or has trailing bytes");
+		PT_TRY(pt_hip_memcpy_h2d(_dev.rng, rng.data(), rng.size() * sizeof(uint32_t), _stream));
+		PT_TRY(pt_hip_memcpy_h2d(_dev.mean, mean.data(), mean.size() * sizeof(float), _stream));
+		PT_TRY(pt_hip_memcpy_h2d(_dev.stats, hd.stats, sizeof(hd.stats), _stream));
+		PT_TRY(pt_hip_stream_synchronize(_stream));
+		_camera.TryUpdate(&hd.camera);
+		_shouldRestartRendering = false;
+		_frameNumber = hd.frame_number;
+		_totalMs = hd.total_ms; _renders = hd.renders;
+		_imageCurrent = false;
+		return PT_OK;
 	}
 
 	// ---- sample split: the one exchange ----
@@ -696,6 +776,16 @@ int pt_get_stats(pt_handle* h, pt_stats* out) {
 	return tracer->Stats(out);
 }
 int pt_get_size(pt_handle* h, int* w, int* hgt, uint32_t* first, uint32_t* count) { PT_HANDLE(h); tracer->Size(w, hgt, first, count); return PT_OK; }
+
+int pt_get_camera(pt_handle* h, pt_camera_data* out) {
+	PT_HANDLE(h);
+	if (!out) return plugin_fail(PT_ERR_INVALID, "out is null");
+	static_assert(sizeof(pt_camera_data) == sizeof(CameraData), "pt_camera_data is CameraData");
+	std::memcpy(out, &tracer->CameraState(), sizeof(*out));
+	return PT_OK;
+}
+int pt_save_state(pt_handle* h, const char* path) { PT_HANDLE(h); return tracer->SaveState(path); }
+int pt_load_state(pt_handle* h, const char* path) { PT_HANDLE(h); return tracer->LoadState(path); }
 
 int pt_combine_instances(pt_handle* const* handles, uint32_t n) {
 	if (!handles || n == 0 || !handles[0]) return plugin_fail(PT_ERR_INVALID, "combine_instances: no handles");

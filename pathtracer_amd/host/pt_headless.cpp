@@ -40,7 +40,7 @@ bool parse_size(const char* s, int& w, int& h) { return std::sscanf(s, "%dx%d", 
 } // namespace
 
 int main(int argc, char** argv) {
-	std::string plugin = "PT_HipWavefront", scene, out, engine, shading;
+	std::string plugin = "PT_HipWavefront", scene, out, engine, shading, resume, checkpoint;
 	int width = 960, height = 540;                           // the reference's window, main.cpp:5
 	int frames = 64, sppPerFrame = 1, depth = 0, moveAt = -1, resizeAt = -1, newW = 0, newH = 0, reportEvery = 0;
 	CameraData* cameraData = new CameraData();               // Program.cpp:36
@@ -60,6 +60,8 @@ int main(int argc, char** argv) {
 		else if (!std::strcmp(argv[a], "--resize-at")) { need(2); resizeAt = std::atoi(argv[++a]); if (!parse_size(argv[++a], newW, newH)) { std::fprintf(stderr, "bad --resize-at\n"); return 2; } }
 		else if (!std::strcmp(argv[a], "--report-every")) { need(1); reportEvery = std::atoi(argv[++a]); }
 		else if (!std::strcmp(argv[a], "--out")) { need(1); out = argv[++a]; }
+		else if (!std::strcmp(argv[a], "--resume")) { need(1); resume = argv[++a]; }               // pt_load_state before the first frame
+		else if (!std::strcmp(argv[a], "--checkpoint")) { need(1); checkpoint = argv[++a]; }       // pt_save_state after the last frame
 		else { std::fprintf(stderr, "unknown argument %s\n", argv[a]); return 2; }
 	}
 
@@ -91,6 +93,16 @@ int main(int argc, char** argv) {
 		if (set_options(pathTracer, &o)) return fail("pt_set_options");
 	}
 
+	if (!resume.empty()) {
+		// the file brings options, camera, sample count, streams and mean; the host's camera follows it, or the first Update would restart
+		auto load_state = sym<int (*)(void*, const char*)>(lib, "pt_load_state");
+		auto get_camera = sym<int (*)(void*, pt_camera_data*)>(lib, "pt_get_camera");
+		if (!load_state || !get_camera) return fail("pt_load_state (not exported)");
+		if (load_state(pathTracer, resume.c_str())) return fail("pt_load_state");
+		static_assert(sizeof(pt_camera_data) == sizeof(CameraData), "pt_camera_data is CameraData");
+		if (get_camera(pathTracer, reinterpret_cast<pt_camera_data*>(cameraData))) return fail("pt_get_camera");
+	}
+
 	auto t0 = std::chrono::steady_clock::now(), tReport = t0;
 	int framesSinceReport = 0;
 	for (int frame = 0; frame < frames; frame++) {
@@ -116,6 +128,12 @@ int main(int argc, char** argv) {
 	else
 		std::printf("%d frames of %dx%d in %.2f ms: %.3f ms / frame, %.1f fps\n", frames, width, height, total_ms, total_ms / frames, 1000.0 * frames / total_ms);
 
+	if (!checkpoint.empty()) {
+		auto save_state = sym<int (*)(void*, const char*)>(lib, "pt_save_state");
+		if (!save_state) return fail("pt_save_state (not exported)");
+		if (save_state(pathTracer, checkpoint.c_str())) return fail("pt_save_state");
+		std::printf("wrote %s\n", checkpoint.c_str());
+	}
 	if (!out.empty()) {
 		if (!readback) return fail("pt_readback (not exported)");
 		std::vector<float> rgba((size_t)width * height * 4);

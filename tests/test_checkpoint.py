@@ -1,0 +1,120 @@
+"""Checkpoint / resume of the accumulation (VERDICT r1 missing item 6; no reference counterpart).
+pt_save_state then pt_load_state on a fresh instance of the same size and scene continues bit for bit: image, RNG streams,
+sample count and ray counters equal those of a run that never stopped."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+CASES = [
+    ("default, fused, reference streams", "default", dict(engine=1), 96, 64),
+    ("default, auto engine", "default", dict(), 96, 64),
+    ("all materials depth 16, wavefront, strided", "materials", dict(engine=0, depth=16, rng_mode=1, stride=2 + 33 * 16, samples_per_pass=4), 80, 48),
+    ("BVH scene, wavefront, reference streams", "synthetic", dict(engine=0), 64, 40),
+    ("sample split, 8 local shards", "default", dict(engine=1, rng_mode=1, stride=35, split_mode=2, split_rank=0, split_ranks=1), 65, 33),
+    ("sample split, rank 1 of 4", "default", dict(engine=0, rng_mode=1, stride=35, split_mode=2, split_rank=1, split_ranks=4, samples_per_pass=2), 65, 33),
+    ("tile split, rank 2 of 3", "default", dict(engine=1, split_mode=1, split_rank=2, split_ranks=3), 50, 30),
+]
+
+
+def _scene(pt, name):
+    if name == "default":
+        return None
+    V, T, M = scenes.all_materials_scene() if name == "materials" else scenes.synthetic_scene(1000)
+    return pt.make_scene(V, T, M)
+
+
+def _snapshot(tr):
+    local, pitch, _ = tr.shard_layout()
+    w, h, first, count = tr.size()
+    raw = np.empty(local * pitch * 4, dtype=np.float32)
+    lib = tr._lib
+    assert lib.pt_hip_memcpy_d2h(raw.ctypes.data, tr.device_mean(), raw.nbytes, None) == 0
+    st = tr.stats()
+    return raw, tr.readback_rng(), (st.frames, st.rays, st.paths, st.diffuse_bounces, st.renders)
+
+
+@pytest.mark.parametrize("what,scene,opts,w,h", CASES, ids=[c[0] for c in CASES])
+def test_resume_continues_bit_for_bit(pt, tmp_path, what, scene, opts, w, h):
+    path = str(tmp_path / "state.bin")
+    cam = pt.CameraData(position=(0.05, -0.02, 0.1, 1.0), rotation=(0.02, 0.05, 0.0, 1.0), fieldOfView=75.0)
+    sc = _scene(pt, scene)
+
+    def fresh():
+        tr = pt.PathTracer(w, h)
+        if sc is not None:
+            tr.set_scene(*sc)
+        return tr
+
+    with fresh() as whole:
+        whole.set_options(**opts)
+        whole.Update(cam)
+        whole.render(3)
+        whole.render(4)
+        want = _snapshot(whole)
+    with fresh() as first:
+        first.set_options(**opts)
+        first.Update(cam)
+        first.render(3)
+        first.save_state(path)
+    assert os.path.getsize(path) > 0 and not os.path.exists(path + ".tmp")
+    with fresh() as second:                       # default options, default camera: the file brings its own
+        second.load_state(path)
+        assert second.stats().frames == 3
+        second.Update(cam)                        # the same camera must not restart (PathTracer.cu:99-101)
+        second.render(4)
+        got = _snapshot(second)
+    assert np.array_equal(bits(got[0]), bits(want[0])), what
+    assert np.array_equal(got[1], want[1])
+    assert got[2] == want[2]
+
+
+def test_state_of_another_size_or_scene_is_refused(pt, tmp_path):
+    path = str(tmp_path / "s.bin")
+    with pt.PathTracer(40, 24) as tr:
+        tr.render(2)
+        tr.save_state(path)
+    with pt.PathTracer(41, 24) as tr:
+        with pytest.raises(pt.PathTracerError, match="saved at 40x24"):
+            tr.load_state(path)
+        tr.render(1)                                  # the refusal is not sticky
+    with pt.PathTracer(40, 24) as tr:
+        tr.set_scene(*pt.make_scene(*scenes.all_materials_scene()))
+        with pytest.raises(pt.PathTracerError, match="another scene"):
+            tr.load_state(path)
+
+
+def test_damaged_state_files_are_refused(pt, tmp_path):
+    path = str(tmp_path / "s.bin")
+    with pt.PathTracer(40, 24) as tr:
+        tr.render(2)
+        tr.save_state(path)
+        data = open(path, "rb").read()
+        for name, blob in (("garbage", b"not a state file" * 40), ("truncated", data[:-5]), ("trailing", data + b"x"), ("empty", b"")):
+            bad = str(tmp_path / name)
+            open(bad, "wb").write(blob)
+            with pytest.raises(pt.PathTracerError):
+                tr.load_state(bad)
+        with pytest.raises(pt.PathTracerError, match="cannot open"):
+            tr.load_state(str(tmp_path / "missing"))
+        with pytest.raises(pt.PathTracerError, match="cannot open"):
+            tr.save_state(str(tmp_path / "no_such_dir" / "s.bin"))
+        tr.load_state(path)                           # and the good file still loads
+        assert tr.stats().frames == 2
+
+
+def test_pending_camera_change_cannot_be_saved(pt, tmp_path):
+    with pt.PathTracer(32, 16) as tr:
+        tr.render(1)
+        tr.Update(pt.CameraData(position=(0.1, 0.0, 0.0, 1.0)))
+        with pytest.raises(pt.PathTracerError, match="camera changed"):
+            tr.save_state(str(tmp_path / "s.bin"))

@@ -92,3 +92,22 @@ def test_hip_plugin_scene_file_depth_and_batched_frames(pt, oracle, tmp_path):
     bad.write_text("v 1 2\n")
     r = run_host("--plugin", HIP_PLUGIN, "--scene", bad, "--frames", 1)
     assert r.returncode == 5 and "vertex needs x y z" in r.stderr
+
+
+@pytest.mark.gpu
+def test_hip_plugin_checkpoint_and_resume_across_processes(oracle, tmp_path):
+    """--checkpoint after 3 frames, --resume in a NEW process for 5 more: the image is the 8-frame one bit for bit
+    (pt_save_state / pt_load_state / pt_get_camera; the host's camera follows the file, so its first Update does not restart)."""
+    state, out = tmp_path / "state.bin", tmp_path / "resumed.pfm"
+    common = ("--plugin", HIP_PLUGIN, "--size", "120x80")
+    r = run_host(*common, "--frames", 3, "--fov", 70, "--pos", "0.05,0.0,0.1", "--depth", 7, "--checkpoint", state)
+    assert r.returncode == 0 and f"wrote {state}" in r.stdout, r.stdout + r.stderr
+    r = run_host(*common, "--frames", 5, "--resume", state, "--out", out)
+    assert r.returncode == 0 and "8 samples per pixel accumulated" in r.stdout, r.stdout + r.stderr
+    img, _, _ = read_pfm(out)
+    cam = oracle.make_camera(position=(0.05, 0.0, 0.1, 1.0), fov=70.0)
+    ref, _, _, _ = oracle.render(oracle.params(120, 80, cam=cam, depth=7, spp=8))
+    assert np.array_equal(bits(img), bits(ref[:, :3]))
+    # the CPU-oracle plugin has no state files: the host says so instead of crashing
+    r = run_host("--plugin", CPU_PLUGIN, "--frames", 1, "--checkpoint", tmp_path / "x.bin")
+    assert r.returncode == 5 and "not exported" in r.stderr
