@@ -244,3 +244,41 @@ def test_wavefront_pass_triangle_soup(pt, oracle, tmp_path):
     ref, _, st, _ = oracle.render(p, scene=oracle.make_scene(V, T, M))
     img, _, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, cam=cam, rng_mode=1, stride=2 + 33 * depth, wavefront=(2, 3))
     assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+
+
+def pixel_corner_scene(oracle, w, h, n_tris, seed):
+    """Triangles whose vertices lie exactly on the rays through PIXEL CORNERS (at random depths), a third of them with two
+    vertices on one pixel row or column: their edges run along pixel boundaries, so for the pixels beside them the
+    rejection tests of RayIntersectsTriangle are zero (to rounding) at the patch corners -- the borderline of
+    primary_need_mask's margin rule ('argued, covered only by random soups')."""
+    rng = np.random.default_rng(seed)
+    c = oracle.camera_corners(oracle.default_camera(), np.float32(w) / np.float32(h))
+    o, tl, bl, br = (np.array([v.x, v.y, v.z], dtype=np.float64) for v in c)
+    V, T = [], []
+    for k in range(n_tris):
+        ij = rng.integers(0, [w + 1, h + 1], (3, 2))
+        if k % 3 == 0: ij[1, 1] = ij[0, 1]              # an edge along a pixel row
+        if k % 3 == 1: ij[2, 0] = ij[0, 0]              # an edge along a pixel column
+        if len({tuple(x) for x in ij}) < 3:
+            ij[2] = (ij[2] + [3, 5]) % [w + 1, h + 1]
+        base = len(V)
+        for i, j in ij:
+            p = tl + (br - bl) * (i / w) + (bl - tl) * (j / h)
+            s = rng.uniform(0.6, 2.5)
+            q = o + (p - o) * s
+            V.append((float(np.float32(q[0])), float(np.float32(q[1])), float(np.float32(q[2])), 1.0))
+        T.append((base, base + 1, base + 2, int(rng.integers(0, 3))))
+        T.append((base + 2, base + 1, base, int(rng.integers(0, 3))))      # both windings: one of the two faces the camera
+    M = [(0, (0.8, 0.7, 0.6, 1.0)), (2, (6.0, 5.0, 4.0, 1.0)), (0, (0.3, 0.5, 0.9, 1.0))]
+    return V, T, M
+
+
+@needs_binary
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_triangles_with_edges_on_pixel_boundaries(pt, oracle, tmp_path, seed):
+    w, h, spp = 64, 40, 4
+    V, T, M = pixel_corner_scene(oracle, w, h, 30, seed)          # 60 triangles: inside the 64-bit need mask
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=6, spp=spp), scene=oracle.make_scene(V, T, M))
+    img, rng, rays = run_host(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=6)
+    assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
+    assert st.rays > w * h * spp * 1.2
