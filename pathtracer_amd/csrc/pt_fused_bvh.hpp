@@ -1,0 +1,164 @@
+// pt_fused_bvh.hpp -- the fused engine on BVH scenes: k_fused_bvh's per-block code (pt_kernels.hip), also compiled for the
+// host by tests/host/fused_bvh_check.cpp (one host thread per lane).
+//
+// The plain fused kernel gives a lane its pixel and runs the pixel's samples and their bounces to the end; on a BVH scene
+// that leaves 16 of 64 lanes busy per instruction (PMC, 10 092 triangles): the camera rays of a wave walk together, but
+// four lanes in ten have no bounce to make and idle through the others' walks, and the walks themselves end at very
+// different times.  Here the wave never leaves the traversal loop (bvh_round, the while-while walk of pt_device.hpp):
+// a lane whose ray is finished is SERVICED -- its hit shaded (kernels.cu:71-94), and then either the bounce ray, or the
+// camera ray of the pixel's next sample, or of the block's next pixel (one LDS counter per block) set up and started --
+// as soon as enough lanes wait for service, while the others keep their place in their walks.  Everything a sample needs
+// stays in registers as before, a pixel's samples still run in order in one lane, so the reference's sequential streams
+// are kept (kernels.cu:25-30: sample s+1 starts where sample s stopped) and the results are the fused kernel's bit for bit.
+#pragma once
+
+#include "pt_device.hpp"
+
+namespace ptd {
+
+// lanes waiting for service at which a wave stops walking to serve them (shade + ray set-up cost about eight node steps,
+// and every service stalls the lanes that are still walking): measured 16 / 24 / 32 / 48, see DESIGN 4.4
+#ifndef PT_FUSED_SERVICE
+#define PT_FUSED_SERVICE 32
+#endif
+
+struct FusedBvhCtx {
+	FrameDev f;
+	BvhView bv;
+	const float4* tris;                  // TriRec array (normals, material indices)
+	const float4* mats;
+	const uint32_t* s_jump;              // step^31 byte tables (LDS)
+	const volatile uint32_t* s_first;    // STRIDED: step^(frame_first * stride) and step^stride as 32 columns each (LDS)
+	const volatile uint32_t* s_per_sample;
+	uint32_t mean_first, n_samples;      // n_samples >= 1
+	uint32_t* rng_io;
+	float4* mean_io;
+};
+
+// The block's pixels are [range_first, range_first + range_count) of the frame's pixel range (local indices); *s_next is
+// zero and a block barrier passed on entry; s_stack is bvh_stack_depth x 256 words.  Every collective below is reached by
+// all lanes of a wave: the loop ends on ballots, never per lane.  n_rays / n_diffuse: this lane's counters (added to).
+template <bool STRIDED>
+__device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t range_first, uint32_t range_count,
+                                                uint32_t* s_stack, uint32_t* s_next, uint32_t& n_rays, uint32_t& n_diffuse) {
+	const FrameDev& f = c.f;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t* stack = s_stack + threadIdx.x;
+	const bool extended = f.shading == PT_SHADING_EXTENDED;
+	// the lane's pixel ...
+	bool have_pixel = false;
+	uint32_t li = 0, px = 0, py = 0, s = 0, rng = 0, start = 0;
+	float4 m = float4{ 0, 0, 0, 0 };
+	// ... its path ...
+	bool has_ray = false;
+	uint32_t b = 0, draws = 0, from_tri = kNoHit, tri = kNoHit;
+	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
+	float best = 0.0f;
+	float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+	// ... and its walk
+	BvhRay r{};
+	int32_t cur = kBvhDone;
+	int sp = 0;
+	bool exhausted = false;              // wave-uniform: the block has no pixel left to hand out
+	for (;;) {
+		const bool walking = cur != kBvhDone;
+		// a lane can be served if its ray is finished, or it has samples to go, or there may be a pixel for it
+		const bool waiting = !walking && (has_ray || have_pixel || !exhausted);
+		const uint32_t n_waiting = (uint32_t)__popcll(__ballot(waiting));
+		const bool any_walking = __any(walking);
+		if (n_waiting >= (uint32_t)PT_FUSED_SERVICE || (!any_walking && n_waiting != 0u)) {
+			bool fresh = false;          // the lane has a new ray to set up
+			if (waiting && has_ray) {
+				// Intersect (kernels.cu:71-94) for the hit `tri` of bounce b
+				float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
+				bool alive = false;
+				if (tri != kNoHit) {
+					from_tri = tri;
+					float4 r2 = c.tris[4 * tri + 2], r3 = c.tris[4 * tri + 3];
+					uint32_t mi = __float_as_uint(r3.x);
+					float4 head = c.mats[2 * mi];
+					uint32_t type = __float_as_uint(head.x);
+					float4 color = c.mats[2 * mi + 1];
+					if (extended && type != PT_MAT_EMISSIVE) {
+						if (shade_extended(type, Vec3{ r2.y, r2.z, r2.w }, color, head.y, best, o, d, step, rng)) { n_diffuse++; draws += 2; }
+						alive = true;
+					} else if (type == PT_MAT_DIFFUSE) {
+						shade_diffuse(Vec3{ r2.y, r2.z, r2.w }, color, best, c.s_jump, o, d, step, rng);
+						n_diffuse++;
+						draws += 33;
+						alive = true;
+					} else if (type == PT_MAT_EMISSIVE) {
+						frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };
+					}
+				}
+				b++;
+				if (alive && b < f.depth) {
+					if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
+					fresh = true;
+				} else {
+					// the sample is complete: DrawToTexture (kernels.cu:4-19), then the stream of the next one
+					m = running_mean(frame, m, c.mean_first + s);
+					if (STRIDED) {
+						if (draws != f.stride) rng = mat_apply_lds(c.s_per_sample, start);
+						start = rng;
+					}
+					s++;
+					has_ray = false;
+				}
+			}
+			// a pixel whose samples are all taken goes back to memory, and the lane asks for another
+			bool want = waiting && !has_ray;
+			if (want && have_pixel) {
+				if (s < c.n_samples) want = false;
+				else {
+					c.mean_io[li] = m;
+					if (!STRIDED) c.rng_io[li] = rng;
+					have_pixel = false;
+				}
+			}
+			const unsigned long long want_mask = __ballot(want);
+			if (want_mask != 0ull && !exhausted) {
+				const uint32_t n_want = (uint32_t)__popcll(want_mask);
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(s_next, n_want);
+				base = __shfl(base, 0, 64);
+				const uint32_t j = base + (uint32_t)__popcll(want_mask & ((1ull << lane) - 1ull));
+				if (base + n_want >= range_count) exhausted = true;          // wave-uniform: nothing left after this hand-out
+				if (want && j < range_count) {
+					li = range_first + j;
+					const uint32_t i = f.pixel_first + li;
+					px = i % (uint32_t)f.width; py = i / (uint32_t)f.width;
+					start = c.rng_io[li];
+					if (STRIDED) start = mat_apply_lds(c.s_first, start);
+					rng = start;
+					m = c.mean_io[li];
+					s = 0;
+					have_pixel = true;
+				}
+			}
+			if (waiting && !has_ray && have_pixel) {
+				// the camera ray of the pixel's sample s (InitializeRays, kernels.cu:32-55); have_pixel implies s < n_samples here
+				o = Vec3{ f.origin.x, f.origin.y, f.origin.z };
+				d = primary_direction(f, px, py, rng);
+				best = FLT_MAX;
+				step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+				draws = 2;
+				from_tri = kNoHit;
+				b = 0;
+				has_ray = true;
+				fresh = true;
+			}
+			if (fresh) {
+				n_rays++;
+				tri = kNoHit;
+				r = bvh_ray_setup(c.bv, o, d, best);
+				bvh_start(c.bv, r, best, from_tri, cur, sp, stack);        // a bounced ray starts at the leaf it leaves
+			}
+		}
+		if (!__any(cur != kBvhDone)) break;      // after a service nobody walks only if nobody had anything left to do
+		PT_TIME_NULL();
+		bvh_round(c.bv, r, o, d, best, tri, cur, sp, stack PT_TIME_ARG);
+	}
+}
+
+} // namespace ptd

@@ -27,6 +27,7 @@
 #include "pt_hip.h"
 #include "pt_device.hpp"
 #include "pt_wavefront.hpp"
+#include "pt_fused_bvh.hpp"
 #include "pt_bvh.hpp"
 
 #pragma clang fp contract(off)
@@ -455,9 +456,11 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f
 			float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
 			uint32_t draws = 2;                      // this sample's RNG draws: 2 + 33 per diffuse bounce
+			uint32_t from_tri = kNoHit;              // the triangle the path's next ray starts on (the BVH walk begins at its leaf)
 			// Intersect (kernels.cu:71-94) for the hit `tri`; true if the path goes on
 			auto shade_hit = [&](uint32_t tri) -> bool {
 				if (tri == kNoHit) return false;
+				from_tri = tri;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
 				uint32_t mi = __float_as_uint(r3.x);
 				float4 head = mats[2 * mi];
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f
 				n_rays++;
 				uint32_t tri = kNoHit;
 				if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
-				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x, from_tri);       // starts at the leaf it leaves
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				alive = shade_hit(tri);
 			}
@@ -512,6 +515,57 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f
 		// sit 128 bytes apart (k_fold_partials adds them into stats[0..1] afterwards).  A same-address atomic per wave was the
 		// floor of this kernel: 64 800 of them at the ~88 per microsecond one word sustains = 0.74 ms per launch, whatever
 		// the sample count (measured: 0.79 ms for 1 spp, 0.81 for 8, 1.12 for 64).
+		__shared__ unsigned long long s_cnt[2];
+		if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+		__syncthreads();
+		for (int off = 32; off > 0; off >>= 1) {
+			n_rays += __shfl_down(n_rays, off, 64);
+			n_diffuse += __shfl_down(n_diffuse, off, 64);
+		}
+		if ((threadIdx.x & 63) == 0) {
+			atomicAdd(&s_cnt[0], (unsigned long long)n_rays);
+			atomicAdd(&s_cnt[1], (unsigned long long)n_diffuse);
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long* slot = stats + PT_STATS_PUBLIC_WORDS + (size_t)(blockIdx.x % kStatsSlots) * kStatsSlotWords;
+			atomicAdd(&slot[0], s_cnt[0]);
+			atomicAdd(&slot[1], s_cnt[1]);
+			if (blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_samples * f.pixel_count);
+		}
+	}
+}
+
+// The fused engine on BVH scenes: persistent walks with in-register service of finished rays (pt_fused_bvh.hpp).
+// Block b owns the pixels [b * range, ...) of the frame's range and hands them to its lanes as they free up.
+#ifndef PT_FUSED_BVH_WAVES
+#define PT_FUSED_BVH_WAVES 5
+#endif
+
+template <bool STRIDED>
+__global__ __launch_bounds__(kBlock, PT_FUSED_BVH_WAVES) void k_fused_bvh(FrameDev f, const unsigned char* __restrict__ scene,
+                                                      uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
+                                                      uint32_t mean_first, uint32_t n_samples, uint32_t range,
+                                                      uint32_t* __restrict__ rng_io, float4* __restrict__ mean_io,
+                                                      unsigned long long* __restrict__ stats) {
+	extern __shared__ float4 s_dyn[];
+	uint32_t* s_stack = reinterpret_cast<uint32_t*>(s_dyn);        // bvh_stack_depth x 256 words
+	__shared__ uint32_t s_jump[1024];
+	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1];
+	__shared__ uint32_t s_next;
+	if (STRIDED && threadIdx.x < 32) { s_first[threadIdx.x] = first.cols[threadIdx.x]; s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x]; }
+	if (threadIdx.x == 0) s_next = 0;
+	stage_jump31(s_jump);
+	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
+	FusedBvhCtx c{ f, make_bvh_view(scene, n_tris, n_mats, f.origin), tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_per_sample,
+	               mean_first, n_samples, rng_io, mean_io };
+	__syncthreads();
+	uint32_t n_rays = 0, n_diffuse = 0;
+	const uint32_t range_first = blockIdx.x * range;
+	const uint32_t range_count = range_first < f.pixel_count ? min(range, f.pixel_count - range_first) : 0u;
+	fused_bvh_block<STRIDED>(c, range_first, range_count, s_stack, &s_next, n_rays, n_diffuse);
+	if (stats) {
+		// as in k_fused: wave reduce -> block reduce in LDS -> one pair of global atomics per block into one of kStatsSlots partial sums
 		__shared__ unsigned long long s_cnt[2];
 		if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
 		__syncthreads();
@@ -620,6 +674,8 @@ size_t carve(Workspace* w, unsigned char* base, uint32_t pixel_count, uint32_t s
 }
 
 uint32_t g_bvh_min_tris = kBvhMinTris;       // pt_hip_set_bvh_threshold: scenes packed from now on
+// measurement / test knob (read per call): PT_FUSED_BVH_PLAIN in the environment = k_fused<*, 2>, the lane-per-pixel form, on BVH scenes
+bool fused_bvh_plain() { return std::getenv("PT_FUSED_BVH_PLAIN") != nullptr; }
 // recorded per scene at pack time (SceneHeader::n_nodes, pt_hip_scene_has_bvh) and passed with the frame
 bool scene_has_bvh(const SceneInfo& s) { return s.bvh; }
 SceneInfo scene_info(const pt_frame* f, uint32_t n_tris, uint32_t n_mats) { return SceneInfo{ n_tris, n_mats, (f->flags & PT_FRAME_SCENE_BVH) != 0 }; }
@@ -758,8 +814,9 @@ int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_tria
 
 size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
 	size_t n = bvh_offset_of(n_triangles, n_materials);
-	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B
-	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes;
+	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B, the
+	// normal classes, and the path lists (one word per triangle + at most one list per triangle)
+	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes + bvh_paths_bytes(n_triangles);
 	return n;
 }
 
@@ -812,6 +869,16 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			static_assert(sizeof(ptbvh::ClassBlock) == kBvhClassBytes && ptbvh::kMaxClasses == kBvhMaxClasses && ptbvh::kKappaLo == kBvhKappaLo,
 			              "pt_bvh.hpp and pt_device.hpp disagree on the normal classes");
 			std::memcpy(base + hdr.leaf_offset + (size_t)n_triangles * 64u, &bvh.classes, sizeof(bvh.classes));
+			{
+				// path lists: tri_path, then the lists (pt_bvh.hpp build_paths; ptd::bvh_paths_bytes reserved for them)
+				unsigned char* pp = base + hdr.leaf_offset + (size_t)n_triangles * 64u + kBvhClassBytes;
+				if (bvh.paths.tri_path.size() != n_triangles || bvh.paths.words.size() > (size_t)n_triangles * bvh_path_words(n_triangles))
+					return fail(PT_ERR_LIMIT, "scene_pack: path lists larger than their reservation");
+				for (uint32_t e : bvh.paths.tri_path)
+					if ((e & 3u) || e >= bvh.paths.words.size()) return fail(PT_ERR_LIMIT, "scene_pack: a path list is misplaced");
+				std::memcpy(pp, bvh.paths.tri_path.data(), bvh.paths.tri_path.size() * 4u);
+				std::memcpy(pp + bvh_tri_path_bytes(n_triangles), bvh.paths.words.data(), bvh.paths.words.size() * 4u);
+			}
 			for (int k = 0; k < 3; k++) hdr.center[k] = bvh.center[k];
 			hdr.radius = bvh.radius;
 			hdr.kappa_root = bvh.kappa_root;
@@ -1142,7 +1209,27 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	dim3 grid((unsigned)(((size_t)frame->pixel_count + kBlock - 1) / kBlock)), block(kBlock);
 #define PT_FUSED(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
-	if (strided) { if (mode == 2) PT_FUSED(true, 2); else if (mode == 1) PT_FUSED(true, 1); else PT_FUSED(true, 0); }
+	if (mode == 2 && !fused_bvh_plain()) {
+		// BVH scenes: the persistent form (pt_fused_bvh.hpp).  A block owns `range` pixels and hands them to its lanes as they
+		// free up; a lane also refills from its own pixel's remaining samples.  With many samples per call that alone keeps
+		// the lanes busy and short ranges (more blocks) balance best; with one sample per call -- the reference's frame loop --
+		// the pixel queue is all there is, and longer ranges win.  Measured at 1080p on 10 092 / 99 372 triangles, Mrays/s:
+		// 1 sample per call: 256 pixels 5140 / 3590, 512: 6330 / 4460, 832: 7440 / 5310, 1664: 7910 / 6040, 3328: 5400 / 3890
+		// (too few blocks); 16 samples: 9070 / 6490, 9260 / 6660, 8970 / 7140, 8940 / 6640, 5550 / 3950.  So the grid covers
+		// the machine's resident blocks once (one sample per call) or twice over, never with less than a pixel per lane.
+		const char* env_range_s = std::getenv("PT_FUSED_RANGE");                                       // measurement knob
+		const uint32_t env_range = env_range_s ? (uint32_t)std::atoi(env_range_s) : 0u;
+		const uint32_t resident = (uint32_t)grid_for((size_t)1 << 40) / 8u * (uint32_t)PT_FUSED_BVH_WAVES;      // CUs x blocks per CU
+		const uint32_t fill = n_samples >= 2u ? 2u : 1u;
+		const uint32_t range = env_range ? std::max(env_range, 1u)
+		                                 : (uint32_t)std::max<size_t>(kBlock, ((size_t)frame->pixel_count / ((size_t)resident * fill) + 63) / 64 * 64);
+		dim3 pgrid((unsigned)(((size_t)frame->pixel_count + range - 1) / range));
+#define PT_FUSED_BVH(STR) hipLaunchKernelGGL((k_fused_bvh<STR>), pgrid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
+	mean_first, n_samples, range, rng, (float4*)mean, (unsigned long long*)stats)
+		if (strided) PT_FUSED_BVH(true); else PT_FUSED_BVH(false);
+#undef PT_FUSED_BVH
+	}
+	else if (strided) { if (mode == 2) PT_FUSED(true, 2); else if (mode == 1) PT_FUSED(true, 1); else PT_FUSED(true, 0); }
 	else { if (mode == 2) PT_FUSED(false, 2); else if (mode == 1) PT_FUSED(false, 1); else PT_FUSED(false, 0); }
 #undef PT_FUSED
 	if (stats) hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (unsigned long long*)stats);

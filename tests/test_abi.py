@@ -137,8 +137,15 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     n_tris, n_nodes, bvh_off, leaf_off = int(hdr_u[0]), int(hdr_u[6]), int(hdr_u[7]), int(hdr_u[8])
     assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 32 * n_tris
     assert hdr_f[12] > 0 and hdr_f[13] > 0                       # radius, kappa_root
-    # QNode, 32 bytes: 12 uint16 grid coordinates -- per child and axis {lo, hi} -- + two child words; the grid is bvh_grid(center, radius)
-    assert n == bvh_off + (32 + 64) * n_tris + 192               # the blob: header, triangles, materials | nodes | leaf records | normal classes
+    # QNode, 32 bytes = two half nodes of {3 words {lo, hi} uint16 grid coordinates, child word}; the grid is bvh_grid(center, radius)
+    balanced, k = 0, n_tris
+    while k > 4:
+        k, balanced = (k + 1) // 2, balanced + 1
+    stack_depth = max(balanced, 1) + 3
+    path_words = (2 + stack_depth + 3) & ~3
+    tri_path_bytes = (4 * n_tris + 63) & ~63
+    # the blob: header, triangles, materials | nodes | leaf records | normal classes | tri_path | path lists
+    assert n == bvh_off + (32 + 64) * n_tris + 192 + tri_path_bytes + n_tris * path_words * 4
     # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis, tau}: every triangle's plane lies in one of the cones, and
     # |cos(axis, normal)| >= cos(half-angle) with tau = sin(half-angle + asin(0.02)) (+ margins) for all of its members
     cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 192]
@@ -171,6 +178,10 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     kappa_root = float(hdr_f[13])
 
     deepest = [0]
+    pbase = leaf_off + 64 * n_tris + 192
+    tri_path = raw[pbase:pbase + 4 * n_tris].view(np.uint32)
+    paths = raw[pbase + tri_path_bytes:pbase + tri_path_bytes + n_tris * path_words * 4].view(np.uint32)
+    trail = []
 
     def visit(child, lo, hi, depth=1):
         """checks containment: a quantised box holds its subtree's vertices EXACTLY (corners rounded outward, no tolerance)
@@ -180,6 +191,11 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
             first, count = code >> 3, (code & 7) + 1
             for k in range(first, first + count):
                 seen[k] += 1
+                # path list of the leaf (pt_bvh.hpp build_paths): {n, leaf code, siblings root side first, 0 padding}, 16-byte aligned
+                at = int(tri_path[orig[k]])
+                assert at % 4 == 0 and int(paths[at]) == len(trail) and int(paths[at + 1].view(np.int32)) == child
+                assert paths[at + 2:at + 2 + len(trail)].tolist() == trail
+                assert not paths[at + 2 + len(trail):(at + 2 + len(trail) + 3) & ~3].any()
                 tri = Tm[orig[k]]
                 pts = P[tri[:3]]
                 assert (pts.astype(np.float64) >= lo).all() and (pts.astype(np.float64) <= hi).all()
@@ -188,12 +204,15 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
                 assert kappa_root >= 16 * 2.0**-24 / 1e-6 * np.linalg.norm(e0) * np.linalg.norm(e1) * (1 - 1e-5)
             return
         q, ni = nodes_q[child].astype(np.float64), nodes_i[child]
-        lo0, hi0, lo1, hi1 = glo + q[0:6:2] * cell, glo + q[1:6:2] * cell, glo + q[6:12:2] * cell, glo + q[7:12:2] * cell
+        lo0, hi0, lo1, hi1 = glo + q[0:6:2] * cell, glo + q[1:6:2] * cell, glo + q[8:14:2] * cell, glo + q[9:14:2] * cell
         assert (lo0 >= lo).all() and (hi0 <= hi).all() and (lo1 >= lo).all() and (hi1 <= hi).all()
         # outward rounding costs at most one cell per face
         deepest[0] = max(deepest[0], depth)
-        visit(int(ni[6]), lo0, hi0, depth + 1)
+        trail.append(2 * child + 1)                                  # going to child 0: the sibling is half node 2 * node + 1
+        visit(int(ni[3]), lo0, hi0, depth + 1)
+        trail[-1] = 2 * child
         visit(int(ni[7]), lo1, hi1, depth + 1)
+        trail.pop()
 
     import sys
     sys.setrecursionlimit(10000)
@@ -201,9 +220,6 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     assert (seen == 1).all()
     # the traversal's stack is sized from the triangle count alone (bvh_stack_depth: balanced depth of 4-triangle leaves + 3
     # levels of slack for surface-area splits); the builder must stay inside it
-    balanced, n = 0, n_tris
-    while n > 4:
-        n, balanced = (n + 1) // 2, balanced + 1
     assert 0 < deepest[0] <= balanced + 3
     # the knob: brute force only
     assert lib.pt_hip_set_bvh_threshold(0xFFFFFFFF) == 0

@@ -585,3 +585,35 @@ def test_brute_force_scene_at_the_lds_limit(pt, oracle, name, engine, brute_forc
         img, st = tr.readback(), tr.stats()
     assert_bit_equal(img, ref, name)
     assert st.rays == st_ref.rays
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strided", [False, True], ids=["sequential", "strided"])
+def test_fused_engine_on_bvh_scenes_persistent_and_plain_forms_agree(pt, oracle, strided):
+    """k_fused_bvh (pt_fused_bvh.hpp: persistent walks, finished rays serviced at a quorum, pixels handed out per block --
+    what the fused engine runs on BVH scenes) and k_fused<*, 2> (a lane per pixel to the end; PT_FUSED_BVH_PLAIN in the
+    environment) both give the oracle's image, streams and ray count; one sample per call (the reference's frame loop: the
+    pixel queue is the only refill) and many."""
+    import os
+    V, T, M = scenes.synthetic_scene(2500)
+    w, h, depth = 333, 187, 10                       # 62 271 pixels: several blocks, a ragged last range
+    kw = dict(rng_mode=pt.PT_RNG_STRIDED, stride=2 + 33 * depth) if strided else {}
+    okw = dict(rng_mode=oracle.RNG_STRIDED, stride=2 + 33 * depth) if strided else {}
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, depth=depth, spp=6, **okw), scene=oracle.make_scene(V, T, M))
+    for plain in (False, True):
+        if plain:
+            os.environ["PT_FUSED_BVH_PLAIN"] = "1"
+        try:
+            with pt.PathTracer(w, h) as tr:
+                tr.set_scene(*pt.make_scene(V, T, M))
+                tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth, **kw)
+                tr.render(1)
+                tr.render(5)
+                img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+        finally:
+            os.environ.pop("PT_FUSED_BVH_PLAIN", None)
+        diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+        assert not diff.any(), f"plain={plain}: {int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+        assert st.rays == st_ref.rays and st.diffuse_bounces * 33 + st.paths * 2 == st_ref.draws
+        if not strided:
+            assert np.array_equal(rng, ref_rng)
