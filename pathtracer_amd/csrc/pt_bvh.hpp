@@ -56,8 +56,8 @@ static_assert(sizeof(Node) == 64, "BVH node is 4 float4");
 // inflated for the scene's largest kappa, which is what the deepest boxes -- most of the tests -- needed anyway.
 struct QNode {
 	uint16_t box0[3][2];        // child 0: per axis {lo, hi}: one 32-bit word per axis, lo in its low half
-	int32_t child0;             // as Node: the child's box and its reference share one 16-byte half of the node, so that
-	uint16_t box1[3][2];        // child 1      a traversal that needs ONE child (path lists, below) reads one half
+	int32_t child0;             // as Node: a child's box and its reference share one 16-byte half of the node
+	uint16_t box1[3][2];        // child 1
 	int32_t child1;
 };
 static_assert(sizeof(QNode) == 32, "quantised BVH node is 2 x 16 bytes");
@@ -91,16 +91,10 @@ struct ClassBlock {                                // 192 bytes at the end of th
 };
 static_assert(sizeof(ClassBlock) == 192, "class block is 192 bytes");
 
-struct Paths {                          // path lists, see build_paths
-	std::vector<uint32_t> tri_path;     // n_tris: word offset of the list of the leaf a triangle (original index) lies in
-	std::vector<uint32_t> words;        // the lists
-};
-
 struct Built {
 	ClassBlock classes{};
 	std::vector<Node> nodes;
 	std::vector<LeafTri> tris;
-	Paths paths;
 	float center[3] = { 0, 0, 0 };
 	float radius = 0.0f;
 	float kappa_root = 0.0f;
@@ -330,51 +324,6 @@ inline uint32_t inner_depth(const std::vector<Node>& nodes) {
 	return deepest;
 }
 
-// ---- path lists: a traversal that starts at a LEAF ----
-// A ray that leaves a surface (every ray but the camera's) starts inside the boxes of all ancestors of the leaf its origin
-// triangle lies in: the walk from the root enters them one after the other, half of its node steps on the 10^4..10^5-
-// triangle scenes, each a dependent 32-byte fetch that tests two boxes of which one is known to be hit.  The SIBLINGS
-// hanging off that root-to-leaf path, plus the leaf itself, partition the tree -- so a traversal may just as well start
-// with those siblings on its stack (each box-tested as usual, the shallowest pushed first) and the leaf as its current
-// node.  This is true for the path of ANY leaf, whatever the ray: the hint only decides how much is culled early, never
-// the result.  Per leaf, 16-byte aligned: {n, leaf code, e[0], e[1]} {e[2..5]} ..; an entry is the index of the
-// sibling's 16-byte half node (2 * node + child), root side first; padding entries are 0 (a valid half node, not tested).
-// tri_path[original triangle index] = the word offset of its leaf's list.
-inline uint32_t path_words_per_leaf(uint32_t stack_depth) { return (2u + stack_depth + 3u) & ~3u; }      // what the blob reserves per triangle (>= per leaf)
-inline void paths_visit(const std::vector<Node>& nodes, const std::vector<LeafTri>& tris, uint32_t n_tris, int32_t node,
-                        std::vector<uint32_t>& trail, std::vector<char>& seen, Paths& out) {
-	const Node& nd = nodes[(size_t)node];
-	const int32_t child[2] = { nd.child0, nd.child1 };
-	for (int k = 0; k < 2; k++) {
-		trail.push_back(2u * (uint32_t)node + (uint32_t)(1 - k));        // the sibling of the branch taken here
-		if (child[k] >= 0) paths_visit(nodes, tris, n_tris, child[k], trail, seen, out);
-		else {
-			uint32_t code = (uint32_t)~child[k], first = code >> 3, count = (code & 7u) + 1u;
-			uint32_t at = (uint32_t)out.words.size();
-			out.words.push_back((uint32_t)trail.size());
-			out.words.push_back((uint32_t)child[k]);
-			for (uint32_t e : trail) out.words.push_back(e);
-			while (out.words.size() & 3u) out.words.push_back(0u);
-			for (uint32_t j = 0; j < count && first + j < n_tris; j++) {
-				uint32_t orig;
-				std::memcpy(&orig, &tris[first + j].f[9], 4);
-				// (the wrapped single-leaf root lists triangle 0 in a second, dummy leaf: the real one comes first and keeps it)
-				if (orig < n_tris && !seen[orig]) { out.tri_path[orig] = at; seen[orig] = 1; }
-			}
-		}
-		trail.pop_back();
-	}
-}
-inline Paths build_paths(const std::vector<Node>& nodes, const std::vector<LeafTri>& tris, uint32_t n_tris) {
-	Paths out;
-	out.tri_path.assign(n_tris, 0u);
-	if (nodes.empty()) return out;
-	std::vector<uint32_t> trail;
-	std::vector<char> seen(n_tris, 0);
-	paths_visit(nodes, tris, n_tris, 0, trail, seen, out);       // recursion depth = tree depth <= ptd::bvh_stack_depth
-	return out;
-}
-
 // stack_depth: ptd::bvh_stack_depth(n_tris), what the traversal's stack holds
 inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, uint32_t stack_depth) {
 	Built out;
@@ -445,7 +394,6 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, ui
 		f[6] = v2.x - v0.x; f[7] = v2.y - v0.y; f[8] = v2.z - v0.z;     // edge1 (:66)
 		std::memcpy(&f[9], &i, 4);
 	}
-	out.paths = build_paths(out.nodes, out.tris, n_tris);
 	return out;
 }
 

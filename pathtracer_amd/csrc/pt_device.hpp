@@ -184,19 +184,14 @@ __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 	return (d < 1u ? 1u : d) + kBvhDepthSlack;
 }
 
-constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block,
-constexpr uint32_t kBvhClassBytes = 192;    // pt_bvh.hpp ClassBlock      then the path lists (bvh_paths_bytes)
+constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block
+constexpr uint32_t kBvhClassBytes = 192;    // pt_bvh.hpp ClassBlock
 constexpr uint32_t kBvhMaxClasses = 8;      // == ptbvh::kMaxClasses
 constexpr float kBvhKappaLo = 11.0f * 5.9604645e-8f / (0.02f * 0.25f);     // == ptbvh::kKappaLo: inflation per unit of S for a ray that grazes nothing
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
-// path lists (pt_bvh.hpp build_paths): tri_path[n_tris] (words, padded to 64 bytes), then at most one list of
-// bvh_path_words(n_tris) words per leaf, and there are no more leaves than triangles
-__host__ __device__ inline uint32_t bvh_path_words(uint32_t n_tris) { return (2u + bvh_stack_depth(n_tris) + 3u) & ~3u; }
-__host__ __device__ inline uint32_t bvh_tri_path_bytes(uint32_t n_tris) { return (n_tris * 4u + 63u) & ~63u; }
-__host__ __device__ inline size_t bvh_paths_bytes(uint32_t n_tris) { return (size_t)bvh_tri_path_bytes(n_tris) + (size_t)n_tris * bvh_path_words(n_tris) * 4u; }
-constexpr uint32_t kSceneMagic = 0x50544854u;  // "PTHT" (T: half nodes + path lists; a blob of the older layout is refused)
+constexpr uint32_t kSceneMagic = 0x50544854u;  // "PTHT" (T: half nodes {box, child}; a blob of the older node layout is refused)
 
 // The 16-bit grid the BVH's boxes are stored on (pt_bvh.hpp QNode): a cube around the scene's bounding sphere,
 // x = lo + q * cell, q = 0..65535.  Host (scene_pack) and device evaluate this same function.
@@ -307,8 +302,6 @@ struct BvhView {
 	const float4* classes;   // pt_bvh.hpp NormalClass {axis, tau} x n_classes (wave-uniform reads)
 	uint32_t n_classes;      // 0: no ray is ever "calm" (slivers, or more plane directions than classes)
 	uint32_t n_nodes, n_tris; // sizes of `nodes` and `leaves`
-	const uint32_t* tri_path; // path lists (pt_bvh.hpp build_paths): word offset into `paths` per original triangle index
-	const uint32_t* paths;
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -337,8 +330,6 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	const uint32_t* cb = reinterpret_cast<const uint32_t*>(scene + off + (size_t)n_tris * (kBvhNodeBytes + 64u));
 	v.n_classes = cb[1] != 0u ? (cb[0] < kBvhMaxClasses ? cb[0] : kBvhMaxClasses) : 0u;      // {n_classes, all_classified, ..}
 	v.classes = reinterpret_cast<const float4*>(cb + 4);
-	v.tri_path = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(cb) + kBvhClassBytes);
-	v.paths = v.tri_path + bvh_tri_path_bytes(n_tris) / 4u;
 	return v;
 }
 
@@ -577,49 +568,11 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 	}
 }
 
-// Start of a traversal at the leaf of triangle `hint` instead of at the root (pt_bvh.hpp, path lists): the siblings along
-// the root-to-leaf path are box-tested -- independent 16-byte fetches, four in flight, instead of one dependent 32-byte
-// fetch per level, and one box per level instead of two -- and the ones the ray can reach go on the stack, root side first,
-// so that the deepest (nearest) is popped first; the leaf becomes the current node.  Any valid hint gives the same result
-// (the siblings and the leaf partition the tree); a good one -- the triangle the ray starts on -- saves half of the walk.
-#ifndef PT_BVH_PATHS
-#define PT_BVH_PATHS 1
-#endif
-
-__device__ __forceinline__ void bvh_start(const BvhView& bv, const BvhRay& r, float best_t, uint32_t hint, int32_t& cur, int& sp, uint32_t* stack) {
-	cur = 0; sp = 0;
-	if (!PT_BVH_PATHS || hint >= bv.n_tris) return;                 // camera rays, stale or missing hints: from the root
-	const uint4* list = reinterpret_cast<const uint4*>(bv.paths + bv.tri_path[hint]);
-	const uint4 head = list[0];
-	const uint32_t n = head.x;
-	const float thi = best_t + r.dt + 1e-6f * best_t;
-	auto test = [&](uint4 half, bool on) {
-		float tn;
-		if (on && box_hit(half.x, half.y, half.z, r, thi, tn) && sp < bv.stack_depth) { stack[sp * 256] = half.w; sp++; }
-	};
-	{
-		uint4 h0 = bv.nodes[head.z], h1 = bv.nodes[head.w];
-		test(h0, 0u < n);
-		test(h1, 1u < n);
-	}
-	for (uint32_t k = 2u, g = 1u; k < n; k += 4u, g++) {
-		const uint4 e = list[g];
-		uint4 h0 = bv.nodes[e.x], h1 = bv.nodes[e.y], h2 = bv.nodes[e.z], h3 = bv.nodes[e.w];
-		test(h0, k < n);
-		test(h1, k + 1u < n);
-		test(h2, k + 2u < n);
-		test(h3, k + 3u < n);
-	}
-	cur = (int32_t)head.y;
-}
-
-// hint: a triangle near the ray's origin (the one it leaves), or kNoHit
 __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
-                                              uint32_t* stack, uint32_t hint = kNoHit) {
+                                              uint32_t* stack) {
 	BvhRay r = bvh_ray_setup(bv, o, d, best_t);
-	int32_t cur;
-	int sp;
-	bvh_start(bv, r, best_t, hint, cur, sp, stack);
+	int32_t cur = 0;
+	int sp = 0;
 	PT_TIME_NULL();
 	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack PT_TIME_ARG);
 }
@@ -675,8 +628,9 @@ __device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origi
 					best = FIRST ? FLT_MAX : b.z;
 					tri = kNoHit;
 					r = bvh_ray_setup(bv, o, d, best);
-					// (from the root: starting at the origin triangle's leaf -- bvh_start, as k_fused does -- was measured here and lost 3-4 %:
-					// the sibling tests lengthen the refill, which stalls the lanes that are still walking, and cost the kernel a spill)
+					// (from the root.  Starting at the leaf of the triangle the ray leaves -- the siblings along that leaf's root path
+					// box-tested and stacked, which spares half of a bounced ray's node steps -- was built and measured, DESIGN 4.4:
+					// -3..-4 % here and -4..-8 % in k_fused_bvh: the tests lengthen the refill, which stalls the lanes still walking)
 					cur = 0; sp = 0; has_ray = true;
 				}
 			}

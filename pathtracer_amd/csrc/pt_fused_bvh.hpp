@@ -51,7 +51,7 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 	float4 m = float4{ 0, 0, 0, 0 };
 	// ... its path ...
 	bool has_ray = false;
-	uint32_t b = 0, draws = 0, from_tri = kNoHit, tri = kNoHit;
+	uint32_t b = 0, draws = 0, tri = kNoHit;
 	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
 	float best = 0.0f;
 	float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
@@ -73,7 +73,6 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 				float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
 				bool alive = false;
 				if (tri != kNoHit) {
-					from_tri = tri;
 					float4 r2 = c.tris[4 * tri + 2], r3 = c.tris[4 * tri + 3];
 					uint32_t mi = __float_as_uint(r3.x);
 					float4 head = c.mats[2 * mi];
@@ -143,7 +142,6 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 				best = FLT_MAX;
 				step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
 				draws = 2;
-				from_tri = kNoHit;
 				b = 0;
 				has_ray = true;
 				fresh = true;
@@ -152,7 +150,7 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 				n_rays++;
 				tri = kNoHit;
 				r = bvh_ray_setup(c.bv, o, d, best);
-				bvh_start(c.bv, r, best, from_tri, cur, sp, stack);        // a bounced ray starts at the leaf it leaves
+				cur = 0; sp = 0;
 			}
 		}
 		if (!__any(cur != kBvhDone)) break;      // after a service nobody walks only if nobody had anything left to do

@@ -456,11 +456,9 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f
 			float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
 			uint32_t draws = 2;                      // this sample's RNG draws: 2 + 33 per diffuse bounce
-			uint32_t from_tri = kNoHit;              // the triangle the path's next ray starts on (the BVH walk begins at its leaf)
 			// Intersect (kernels.cu:71-94) for the hit `tri`; true if the path goes on
 			auto shade_hit = [&](uint32_t tri) -> bool {
 				if (tri == kNoHit) return false;
-				from_tri = tri;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
 				uint32_t mi = __float_as_uint(r3.x);
 				float4 head = mats[2 * mi];
@@ -495,7 +493,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f
 				n_rays++;
 				uint32_t tri = kNoHit;
 				if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
-				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x, from_tri);       // starts at the leaf it leaves
+				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				alive = shade_hit(tri);
 			}
@@ -814,9 +812,8 @@ int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_tria
 
 size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
 	size_t n = bvh_offset_of(n_triangles, n_materials);
-	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B, the
-	// normal classes, and the path lists (one word per triangle + at most one list per triangle)
-	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes + bvh_paths_bytes(n_triangles);
+	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B, the normal classes
+	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes;
 	return n;
 }
 
@@ -869,16 +866,6 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			static_assert(sizeof(ptbvh::ClassBlock) == kBvhClassBytes && ptbvh::kMaxClasses == kBvhMaxClasses && ptbvh::kKappaLo == kBvhKappaLo,
 			              "pt_bvh.hpp and pt_device.hpp disagree on the normal classes");
 			std::memcpy(base + hdr.leaf_offset + (size_t)n_triangles * 64u, &bvh.classes, sizeof(bvh.classes));
-			{
-				// path lists: tri_path, then the lists (pt_bvh.hpp build_paths; ptd::bvh_paths_bytes reserved for them)
-				unsigned char* pp = base + hdr.leaf_offset + (size_t)n_triangles * 64u + kBvhClassBytes;
-				if (bvh.paths.tri_path.size() != n_triangles || bvh.paths.words.size() > (size_t)n_triangles * bvh_path_words(n_triangles))
-					return fail(PT_ERR_LIMIT, "scene_pack: path lists larger than their reservation");
-				for (uint32_t e : bvh.paths.tri_path)
-					if ((e & 3u) || e >= bvh.paths.words.size()) return fail(PT_ERR_LIMIT, "scene_pack: a path list is misplaced");
-				std::memcpy(pp, bvh.paths.tri_path.data(), bvh.paths.tri_path.size() * 4u);
-				std::memcpy(pp + bvh_tri_path_bytes(n_triangles), bvh.paths.words.data(), bvh.paths.words.size() * 4u);
-			}
 			for (int k = 0; k < 3; k++) hdr.center[k] = bvh.center[k];
 			hdr.radius = bvh.radius;
 			hdr.kappa_root = bvh.kappa_root;

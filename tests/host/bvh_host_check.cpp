@@ -44,18 +44,13 @@ int main(int argc, char** argv) {
 	for (size_t k = 0; k < n_rays; k++) {
 		const float* r = rays + 7 * k;
 		Vec3 o{ r[0], r[1], r[2] }, d{ r[3], r[4], r[5] };
-		float best_a = r[6], best_b = r[6], best_c = r[6];
-		uint32_t tri_a = kNoHit, tri_b = kNoHit, tri_c = kNoHit;
+		float best_a = r[6], best_b = r[6];
+		uint32_t tri_a = kNoHit, tri_b = kNoHit;
 		intersect_range(tris, 0, n_tris, bv.det_bounded, o, d, best_a, tri_a);
 		bvh_intersect(bv, o, d, best_b, tri_b, stack);
-		// ... and started at the leaf of SOME triangle (pt_bvh.hpp path lists): any hint must give the same answer -- a
-		// pseudo-random one for two rays of three, the triangle the ray would hit (a well-aimed hint) for the third
-		uint32_t hint = k % 3 == 2 && tri_a != kNoHit ? tri_a : (uint32_t)((k * 2654435761ull) % n_tris);
-		bvh_intersect(bv, o, d, best_c, tri_c, stack, hint);
 		hits += tri_a != kNoHit;
-		if (tri_a != tri_b || __float_as_uint(best_a) != __float_as_uint(best_b) || tri_a != tri_c || __float_as_uint(best_a) != __float_as_uint(best_c)) {
-			if (bad < 10) std::fprintf(stderr, "ray %zu: brute force (%u, %.9g) BVH from the root (%u, %.9g) from the leaf of triangle %u (%u, %.9g)\n",
-			                           k, tri_a, best_a, tri_b, best_b, hint, tri_c, best_c);
+		if (tri_a != tri_b || __float_as_uint(best_a) != __float_as_uint(best_b)) {
+			if (bad < 10) std::fprintf(stderr, "ray %zu: brute force (%u, %.9g) BVH (%u, %.9g)\n", k, tri_a, best_a, tri_b, best_b);
 			bad++;
 		}
 	}

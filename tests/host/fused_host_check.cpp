@@ -76,16 +76,14 @@ int main(int argc, char** argv) {
 			float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
 			float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
 			uint32_t draws = 2;
-			uint32_t from_tri = kNoHit;                       // k_fused: a bounced ray's walk starts at the leaf it leaves
 			for (uint32_t b = 0; b < f.depth; b++) {
 				n_rays++;
 				uint32_t tri = kNoHit;
 				if (extended) best = FLT_MAX;
-				if (BVH) bvh_intersect(bv, o, d, best, tri, stack.data(), from_tri);
+				if (BVH) bvh_intersect(bv, o, d, best, tri, stack.data());
 				else if (b == 0 && use_prim) intersect_range_primary(tris, prim.data(), n_tris, det_bounded, d, best, tri, need);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				if (tri == kNoHit) break;
-				from_tri = tri;
 				float4 r2 = tris[4 * tri + 2], r3 = tris[4 * tri + 3];
 				uint32_t mi = __float_as_uint(r3.x);
 				float4 head = mats[2 * mi];

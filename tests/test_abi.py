@@ -141,11 +141,8 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     balanced, k = 0, n_tris
     while k > 4:
         k, balanced = (k + 1) // 2, balanced + 1
-    stack_depth = max(balanced, 1) + 3
-    path_words = (2 + stack_depth + 3) & ~3
-    tri_path_bytes = (4 * n_tris + 63) & ~63
-    # the blob: header, triangles, materials | nodes | leaf records | normal classes | tri_path | path lists
-    assert n == bvh_off + (32 + 64) * n_tris + 192 + tri_path_bytes + n_tris * path_words * 4
+    # the blob: header, triangles, materials | nodes | leaf records | normal classes
+    assert n == bvh_off + (32 + 64) * n_tris + 192
     # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis, tau}: every triangle's plane lies in one of the cones, and
     # |cos(axis, normal)| >= cos(half-angle) with tau = sin(half-angle + asin(0.02)) (+ margins) for all of its members
     cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 192]
@@ -178,10 +175,6 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     kappa_root = float(hdr_f[13])
 
     deepest = [0]
-    pbase = leaf_off + 64 * n_tris + 192
-    tri_path = raw[pbase:pbase + 4 * n_tris].view(np.uint32)
-    paths = raw[pbase + tri_path_bytes:pbase + tri_path_bytes + n_tris * path_words * 4].view(np.uint32)
-    trail = []
 
     def visit(child, lo, hi, depth=1):
         """checks containment: a quantised box holds its subtree's vertices EXACTLY (corners rounded outward, no tolerance)
@@ -191,11 +184,7 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
             first, count = code >> 3, (code & 7) + 1
             for k in range(first, first + count):
                 seen[k] += 1
-                # path list of the leaf (pt_bvh.hpp build_paths): {n, leaf code, siblings root side first, 0 padding}, 16-byte aligned
-                at = int(tri_path[orig[k]])
-                assert at % 4 == 0 and int(paths[at]) == len(trail) and int(paths[at + 1].view(np.int32)) == child
-                assert paths[at + 2:at + 2 + len(trail)].tolist() == trail
-                assert not paths[at + 2 + len(trail):(at + 2 + len(trail) + 3) & ~3].any()
+
                 tri = Tm[orig[k]]
                 pts = P[tri[:3]]
                 assert (pts.astype(np.float64) >= lo).all() and (pts.astype(np.float64) <= hi).all()
@@ -208,11 +197,8 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
         assert (lo0 >= lo).all() and (hi0 <= hi).all() and (lo1 >= lo).all() and (hi1 <= hi).all()
         # outward rounding costs at most one cell per face
         deepest[0] = max(deepest[0], depth)
-        trail.append(2 * child + 1)                                  # going to child 0: the sibling is half node 2 * node + 1
         visit(int(ni[3]), lo0, hi0, depth + 1)
-        trail[-1] = 2 * child
         visit(int(ni[7]), lo1, hi1, depth + 1)
-        trail.pop()
 
     import sys
     sys.setrecursionlimit(10000)

@@ -1,5 +1,6 @@
 // origin_path_probe.cpp -- how much of a bounced ray's BVH walk is spent on the ANCESTORS of the leaf it starts on?
-// (measurement for the "start from the origin leaf's path" idea; host build of the device code, tests/host/hip_shim)
+// (measurement for the "start the walk at the leaf a ray leaves" idea, which was then built and lost: DESIGN 4.4; host build of
+// the device code, tests/host/hip_shim)
 //   g++ -O2 -std=c++17 -ffp-contract=off -Itests/host/hip_shim -Ipathtracer_amd/csrc -Iinclude -o /tmp/origin_path_probe tools/experiments/origin_path_probe.cpp
 //   /tmp/origin_path_probe scene.blob
 #include <cstdio>
@@ -26,8 +27,8 @@ int main(int argc, char** argv) {
 	std::vector<int32_t> parent(n_nodes, -1), leaf_parent(n_tris, -1);
 	std::vector<int> depth(n_nodes, 0);
 	for (uint32_t i = 0; i < n_nodes; i++) {
-		uint4 w1 = bv.nodes[(size_t)i * 2 + 1];
-		int32_t c[2] = { (int32_t)w1.z, (int32_t)w1.w };
+		uint4 w0 = bv.nodes[(size_t)i * 2], w1 = bv.nodes[(size_t)i * 2 + 1];
+		int32_t c[2] = { (int32_t)w0.w, (int32_t)w1.w };        // half nodes {x, y, z, child}
 		for (int k = 0; k < 2; k++) {
 			if (c[k] >= 0) { parent[c[k]] = (int32_t)i; }
 			else {
@@ -74,9 +75,9 @@ int main(int argc, char** argv) {
 				steps++; anc_steps += is_anc[cur];
 				const uint4* nn = bv.nodes + (size_t)cur * 2;
 				uint4 w0 = nn[0], w1 = nn[1];
-				int32_t c0 = (int32_t)w1.z, c1 = (int32_t)w1.w;
+				int32_t c0 = (int32_t)w0.w, c1 = (int32_t)w1.w;
 				float thi = nbest + r.dt + 1e-6f * nbest, tn0, tn1;
-				bool h0 = box_hit(w0.x, w0.y, w0.z, r, thi, tn0), h1 = box_hit(w0.w, w1.x, w1.y, r, thi, tn1);
+				bool h0 = box_hit(w0.x, w0.y, w0.z, r, thi, tn0), h1 = box_hit(w1.x, w1.y, w1.z, r, thi, tn1);
 				if (h0 && h1) { bool f0 = tn0 <= tn1; stack[sp * 256] = (uint32_t)(f0 ? c1 : c0); sp++; cur = f0 ? c0 : c1; }
 				else if (h0) cur = c0; else if (h1) cur = c1; else cur = bvh_pop(stack, sp);
 			} else {
