@@ -176,7 +176,10 @@ def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples
         tracer.set_options(engine=eng, depth=depth, samples_per_pass=samples_per_pass)
     else:
         tracer.set_options(engine=eng, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=samples_per_pass)
-    for _ in range(warmup):
+    # the plugin measures its candidates (fused in step / out of step, wavefront under AUTO) on the first renders after a
+    # restart: those come first, untimed and on top of the W warm-up steps, so that the timed steps run the decided kernels
+    settle = 3
+    for _ in range(settle + warmup):
         tracer.render(spp)
     st0 = tracer.stats()
     t0 = time.perf_counter()
@@ -186,7 +189,7 @@ def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples
         done += 1
     dt = time.perf_counter() - t0
     st = tracer.stats()
-    out = {"steps": done, "ms_per_step": dt / done * 1e3,
+    out = {"steps": done, "untimed_steps": settle + warmup, "ms_per_step": dt / done * 1e3, "fused_out_of_step": int(st.fused_out_of_step),
            "kernel_ms": (st.total_render_ms - st0.total_render_ms) / max(1, st.renders - st0.renders),
            "rays_per_step": (st.rays - st0.rays) / done, "engine_in_use": int(st.engine_in_use),
            "rng": "sequential" if sequential else f"strided/{stride}", "depth": depth}
@@ -200,7 +203,7 @@ def side_figure(pt, counters, sha, workload, engine, w, h, steps=3, warmup=2):
     fig = {"workload": WORKLOADS[workload][3] + f", {w}x{h}, {SPP_PER_STEP} spp per step", "engine": engine, "rng": m["rng"], "depth": m["depth"],
            "value": round(m["rays_per_step"] / (m["kernel_ms"] * 1e-3) / 1e6, 1), "unit": "Mrays/s (device time)",
            "ms_per_step": round(m["ms_per_step"], 3), "kernel_ms": round(m["kernel_ms"], 3), "rays_per_step": int(m["rays_per_step"]),
-           "rays_per_pixel_sample": round(m["rays_per_step"] / (w * h * SPP_PER_STEP), 3)}
+           "rays_per_pixel_sample": round(m["rays_per_step"] / (w * h * SPP_PER_STEP), 3), "fused_out_of_step": m["fused_out_of_step"]}
     fig["roofline"] = valu_roofline(counters, f"{workload}/{engine}", m["kernel_ms"], sha)
     return fig
 
@@ -279,7 +282,7 @@ def main():
                                            "so achieved/peak > 1 only says that traffic is gone (measured_frac = PMC bytes / time / peak)"}
         if not args.bare:
             if args.workload == "default" and sequential:
-                out["parity"] = parity_sample(tracer.readback(), w, h, (args.warmup + m["steps"]) * SPP_PER_STEP)
+                out["parity"] = parity_sample(tracer.readback(), w, h, (m["untimed_steps"] + m["steps"]) * SPP_PER_STEP)
             tracer.Destroy()
             try:
                 with open(os.path.join(ROOT, "profiles", "tolerance.json")) as f:

@@ -65,6 +65,11 @@ enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
  * blob) and is traversed with it.  Recorded per scene at pack time: the launchers dispatch on this bit, never on the
  * process-wide threshold, so a blob packed under one threshold stays valid after pt_hip_set_bvh_threshold changes it. */
 #define PT_FRAME_SCENE_BVH 2u
+/* PT_FRAME_OUT_OF_STEP (pt_hip_render_fused, scenes without a BVH): the 64 pixels of a wave take their samples out of step --
+ * a lane whose path has ended starts its pixel's next sample while its neighbours still bounce -- instead of bounce by bounce
+ * together.  Same results bit for bit; faster where paths differ in length (deep scenes), slower where they do not (the
+ * reference's own scene).  The plugin sets it after measuring both forms (pt_plugin.h, engine). */
+#define PT_FRAME_OUT_OF_STEP 4u
 
 /* Which kernels execute a render call. */
 enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1, PT_ENGINE_AUTO = 2 };     /* AUTO: pt_plugin.h (the plugin measures and picks) */

@@ -38,7 +38,9 @@ typedef struct {
 } pt_camera_data;
 
 typedef struct {
-    uint32_t engine;             /* PT_ENGINE_AUTO (default: probes both, keeps the faster; same bits either way), PT_ENGINE_FUSED or PT_ENGINE_WAVEFRONT */
+    uint32_t engine;             /* PT_ENGINE_AUTO (default: the first renders after a (re)start measure the candidates -- fused in step, fused out of
+                                  * step, wavefront -- and the fastest is kept; same bits whichever runs), PT_ENGINE_FUSED (measures its two forms on
+                                  * scenes without a BVH) or PT_ENGINE_WAVEFRONT */
     uint32_t rng_mode;           /* PT_RNG_SEQUENTIAL (default, the reference) or PT_RNG_STRIDED */
     uint32_t stride;             /* STRIDED: draws reserved per sample (default 35) */
     uint32_t depth;              /* bounce iterations, default 10 (PathTracer.cu:129) */
@@ -78,9 +80,10 @@ typedef struct {
     double   last_render_ms;     /* device time of the last finalized BeginDrawing/pt_render */
     double   total_render_ms;    /* sum of the above since the last restart (HIP events on the plugin's stream) */
     uint64_t renders;            /* finalized BeginDrawing/pt_render submissions since the last restart */
-    uint32_t engine_in_use;      /* the engine option, or under PT_ENGINE_AUTO: the engine chosen (PT_ENGINE_AUTO while still probing) */
-    uint32_t _pad;
-    double   auto_rays_per_ms[2];/* PT_ENGINE_AUTO: what the probes measured, indexed by engine (0 = not probed yet) */
+    uint32_t engine_in_use;      /* the engine option, or under PT_ENGINE_AUTO: the engine chosen (PT_ENGINE_AUTO while still measuring) */
+    uint32_t fused_out_of_step;  /* 1: the fused engine runs its out-of-step form (PT_FRAME_OUT_OF_STEP, pt_hip.h) */
+    double   auto_rays_per_ms[2];/* what the probes measured, indexed by engine: [0] wavefront, [1] fused in step (0 = not probed) */
+    double   fused_out_of_step_rays_per_ms;  /* ... and the fused engine out of step (scenes without a BVH) */
 } pt_stats;
 
 const char* pt_last_error(void);

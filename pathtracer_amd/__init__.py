@@ -29,6 +29,7 @@ PT_MAT_DIFFUSE, PT_MAT_REFLECTIVE, PT_MAT_EMISSIVE = 0, 1, 2
 PT_SHADING_REFERENCE, PT_SHADING_EXTENDED = 0, 1
 PT_FRAME_FAST_DIV = 1
 PT_FRAME_SCENE_BVH = 2
+PT_FRAME_OUT_OF_STEP = 4
 PT_MAX_DEPTH = 32
 PT_STATS_PUBLIC_WORDS = 64
 PT_STATS_WORDS = PT_STATS_PUBLIC_WORDS + 32 * 16
@@ -89,7 +90,8 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("diffuse_bounces", C.c_uint64), ("paths", C.c_uint64), ("frames", C.c_uint64),
                 ("rays_per_bounce", C.c_uint64 * PT_MAX_DEPTH), ("last_render_ms", C.c_double),
                 ("total_render_ms", C.c_double), ("renders", C.c_uint64),
-                ("engine_in_use", C.c_uint32), ("_pad", C.c_uint32), ("auto_rays_per_ms", C.c_double * 2)]
+                ("engine_in_use", C.c_uint32), ("fused_out_of_step", C.c_uint32), ("auto_rays_per_ms", C.c_double * 2),
+                ("fused_out_of_step_rays_per_ms", C.c_double)]
 
 
 assert C.sizeof(Vertex) == 16 and C.sizeof(Triangle) == 16 and C.sizeof(Material) == 48 and C.sizeof(CameraData) == 36

@@ -159,4 +159,117 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 	}
 }
 
+
+// ---- brute-force scenes (triangles in LDS): the samples of a wave's 64 pixels, out of step ----
+// k_fused walks a wave's 64 pixels through their samples in step: camera ray, then bounce after bounce until the LAST lane's
+// path has ended.  On a scene whose paths differ in length -- all materials at depth 16: 18 of 64 lanes busy per instruction
+// (PMC) -- the wave pays every bounce of its longest path with most lanes idle, and a brute-force bounce costs ten times a
+// camera ray (all n triangles against the few its pixel can reach).  Here a lane that has no bounce ray to intersect takes its
+// pixel's next sample instead: a CAMERA phase (ray, culled intersection, shade: cheap) for the lanes that wait, then a BOUNCE
+// phase (the loop over all triangles, shade) for the lanes that hold a bounce ray, so the expensive phase always runs with
+// most lanes busy.  (Waiting for a quorum of lanes before a camera phase only loses: all materials at depth 16, 64 samples
+// per call, quorum 1 / 4 / 8 / 16 / 32 / 48: 30.6 / 29.9 / 29.3 / 29.3 / 27.9 / 24.5 Grays/s.)  A pixel's samples still run in order in its lane: same streams,
+// same bits.  Pays where paths end unevenly; on the reference's own scene (every sample exactly two rays) the plain loop
+// has nothing to gain from it and is kept -- the plugin measures both forms and keeps the faster (pt_plugin.cpp).
+#ifndef PT_FUSED_CAMERA_QUORUM
+#define PT_FUSED_CAMERA_QUORUM 1
+#endif
+constexpr uint32_t kFusedCameraQuorum = PT_FUSED_CAMERA_QUORUM;
+
+struct FusedLdsCtx {
+	FrameDev f;
+	const float4* tris;                  // TriRec array, in LDS (or global through the scalar cache)
+	const float4* mats;
+	const float4* prim;                  // camera-ray records (stage_primary_records), or nullptr: no culled camera intersection
+	const uint32_t* s_jump;
+	const volatile uint32_t* s_per_sample;       // STRIDED: step^stride as 32 columns (LDS)
+	uint32_t n_tris;
+	bool det_bounded;
+	uint32_t mean_first, n_samples;
+};
+
+// One pixel per lane (px, py; `start` = the state its first sample starts from, m = its running mean): takes n_samples
+// samples, returns the mean and leaves the stream state in rng.  Every lane of the wave must call it (ballots inside);
+// `in_range` false: a lane beyond the image, which only takes part in the collectives.
+template <bool STRIDED>
+__device__ __forceinline__ void fused_samples_out_of_step(const FusedLdsCtx& c, bool in_range, uint32_t px, uint32_t py, uint32_t start,
+                                                          uint32_t& rng, float4& m, uint32_t& n_rays, uint32_t& n_diffuse) {
+	const FrameDev& f = c.f;
+	const bool extended = f.shading == PT_SHADING_EXTENDED;
+	const unsigned long long need = c.prim ? primary_need_mask(f, px, py, in_range, c.tris, c.prim, c.n_tris) : ~0ull;
+	uint32_t s = in_range ? 0u : c.n_samples;
+	bool has_ray = false;                // a bounce ray waits to be intersected
+	uint32_t b = 0, draws = 0;
+	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
+	float best = 0.0f;
+	float4 step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+	rng = start;
+	// Intersect (kernels.cu:71-94) for the hit `tri` of the lane's ray; afterwards the lane holds its next bounce ray or its sample is complete
+	auto shade = [&](uint32_t tri) {
+		float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
+		bool alive = false;
+		if (tri != kNoHit) {
+			float4 r2 = c.tris[4 * tri + 2], r3 = c.tris[4 * tri + 3];
+			uint32_t mi = __float_as_uint(r3.x);
+			float4 head = c.mats[2 * mi];
+			uint32_t type = __float_as_uint(head.x);
+			float4 color = c.mats[2 * mi + 1];
+			if (extended && type != PT_MAT_EMISSIVE) {
+				if (shade_extended(type, Vec3{ r2.y, r2.z, r2.w }, color, head.y, best, o, d, step, rng)) { n_diffuse++; draws += 2; }
+				alive = true;
+			} else if (type == PT_MAT_DIFFUSE) {
+				shade_diffuse(Vec3{ r2.y, r2.z, r2.w }, color, best, c.s_jump, o, d, step, rng);
+				n_diffuse++;
+				draws += 33;
+				alive = true;
+			} else if (type == PT_MAT_EMISSIVE) {
+				frame = float4{ step.x * color.x, step.y * color.y, step.z * color.z, step.w * color.w };
+			}
+		}
+		b++;
+		if (alive && b < f.depth) {
+			if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
+			has_ray = true;
+			n_rays++;
+		} else {
+			m = running_mean(frame, m, c.mean_first + s);
+			if (STRIDED) {
+				if (draws != f.stride) rng = mat_apply_lds(c.s_per_sample, start);
+				start = rng;
+			}
+			s++;
+			has_ray = false;
+		}
+	};
+	for (;;) {
+		const bool cam = !has_ray && s < c.n_samples;
+		const uint32_t n_cam = (uint32_t)__popcll(__ballot(cam));
+		const bool any_ray = __any(has_ray);
+		if (n_cam >= kFusedCameraQuorum || (!any_ray && n_cam != 0u)) {
+			if (cam) {
+				o = Vec3{ f.origin.x, f.origin.y, f.origin.z };
+				d = primary_direction(f, px, py, rng);
+				best = FLT_MAX;
+				step = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+				draws = 2;
+				b = 0;
+				n_rays++;
+				uint32_t tri = kNoHit;
+				if (c.prim) intersect_range_primary(c.tris, c.prim, c.n_tris, c.det_bounded, d, best, tri, need);
+				else intersect_range(c.tris, 0, c.n_tris, c.det_bounded, o, d, best, tri);
+				shade(tri);
+			}
+		}
+		if (!__any(has_ray)) {
+			if (!__any(s < c.n_samples)) break;
+			continue;
+		}
+		if (has_ray) {
+			uint32_t tri = kNoHit;
+			intersect_range(c.tris, 0, c.n_tris, c.det_bounded, o, d, best, tri);
+			shade(tri);
+		}
+	}
+}
+
 } // namespace ptd

@@ -405,8 +405,13 @@ __global__ __launch_bounds__(kBlock) void k_fill_f32(float* __restrict__ dst, fl
 // SCENE: 0 = brute force, wave-uniform reads through the scalar cache; 1 = brute force from LDS; 2 = BVH
 // (tried and dropped: the reference's 4 triangles held in SGPRs across the pixel loop with the triangle loop
 // unrolled -- 22 SGPR spills, 169 vs 174 Grays/s)
-template <bool STRIDED, int SCENE>
-__global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
+// OUT_OF_STEP (brute-force scenes): the wave's pixels take their samples out of step (pt_fused_bvh.hpp,
+// fused_samples_out_of_step) instead of bounce by bounce together
+#ifndef PT_FUSED_OOS_WAVES
+#define PT_FUSED_OOS_WAVES 8
+#endif
+template <bool STRIDED, int SCENE, bool OUT_OF_STEP>
+__global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS_WAVES : 8) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
                                                   uint32_t mean_first, uint32_t n_samples,
                                                   uint32_t* __restrict__ rng_io, float4* __restrict__ mean_io,
@@ -446,6 +451,13 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : 8) void k_fused(FrameDev f
 		if (STRIDED) start = mat_apply_lds(s_first, start);
 		uint32_t rng = start;
 		float4 m = mean_io[li];
+		if (OUT_OF_STEP && !BVH) {
+			FusedLdsCtx c{ f, tris, mats, use_prim ? s_prim : nullptr, s_jump, s_per_sample, n_tris, det_bounded, mean_first, n_samples };
+			fused_samples_out_of_step<STRIDED>(c, true, px, py, start, rng, m, n_rays, n_diffuse);
+			mean_io[li] = m;
+			if (!STRIDED) rng_io[li] = rng;
+			continue;
+		}
 		// the triangles this wave's pixels can see at all (none of the lanes here is out of range: the loop bound holds for li)
 		unsigned long long need = ~0ull;
 		if (use_prim) need = primary_need_mask(f, px, py, true, tris, s_prim, n_tris);
@@ -1194,7 +1206,7 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	// grid (145 vs 131 Grays/s at 8 blocks/CU) because the kernel holds 77 VGPRs = 6 waves/SIMD and a
 	// persistent grid sized for 8 leaves a one-third-full tail round.
 	dim3 grid((unsigned)(((size_t)frame->pixel_count + kBlock - 1) / kBlock)), block(kBlock);
-#define PT_FUSED(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
+#define PT_FUSED(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE, false>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
 	if (mode == 2 && !fused_bvh_plain()) {
 		// BVH scenes: the persistent form (pt_fused_bvh.hpp).  A block owns `range` pixels and hands them to its lanes as they
@@ -1215,6 +1227,13 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	mean_first, n_samples, range, rng, (float4*)mean, (unsigned long long*)stats)
 		if (strided) PT_FUSED_BVH(true); else PT_FUSED_BVH(false);
 #undef PT_FUSED_BVH
+	}
+	else if (mode != 2 && ((frame->flags & PT_FRAME_OUT_OF_STEP) || std::getenv("PT_FUSED_OUT_OF_STEP"))) {      // (the environment: measurement knob)
+#define PT_FUSED_OOS(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE, true>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
+	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
+		if (strided) { if (mode == 1) PT_FUSED_OOS(true, 1); else PT_FUSED_OOS(true, 0); }
+		else { if (mode == 1) PT_FUSED_OOS(false, 1); else PT_FUSED_OOS(false, 0); }
+#undef PT_FUSED_OOS
 	}
 	else if (strided) { if (mode == 2) PT_FUSED(true, 2); else if (mode == 1) PT_FUSED(true, 1); else PT_FUSED(true, 0); }
 	else { if (mode == 2) PT_FUSED(false, 2); else if (mode == 1) PT_FUSED(false, 1); else PT_FUSED(false, 0); }

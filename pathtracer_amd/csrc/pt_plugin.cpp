@@ -110,16 +110,32 @@ class PathTracer final : public IPathTracer {
 	uint32_t _frameFlags = 0;           // PT_FRAME_FAST_DIV once both image sizes are verified
 	int _error = PT_OK;                 // sticky: once a device call fails the object stops rendering
 
-	// PT_ENGINE_AUTO.  Both engines return the same bits, so which one runs is a matter of speed only, and that depends
-	// on the scene, the image size and the RNG mode in ways no static rule covers (default scene: fused 235 against 203
-	// Grays/s; all-materials scene with strided streams: wavefront 29.7 against 15.7; BVH scenes at 1080p: wavefront
-	// 1.7x, at 64x40 the staged pipeline's 30 launches per sample lose).  So AUTO measures: after a change of scene,
-	// options or size the first render runs fused, the second wavefront, and from the third on the one that traced more
-	// rays per millisecond of device time (HIP events, device ray counters).  A camera restart keeps the decision.
-	enum AutoPhase { ProbeFused, ProbeWavefront, Decided };
-	AutoPhase _autoPhase = ProbeFused;
-	uint32_t _autoChoice = PT_ENGINE_FUSED, _engineInFlight = PT_ENGINE_FUSED;
-	double _autoRate[2] = { 0.0, 0.0 };     // rays per ms, indexed by engine
+	// Which kernels run a render is a matter of speed only -- every candidate returns the same bits -- and that depends on the
+	// scene, the image size, the samples per call and the RNG mode in ways no static rule covers (default scene: fused 250
+	// against 222 Grays/s; all materials at depth 16: the fused engine out of step 29 against 16 in step; BVH scenes under
+	// the reference's streams: fused 8.5 against 5.7, with strided batches the wavefront engine 10.7; at 64x40 the staged
+	// pipeline's 30 launches per sample lose).  So the plugin MEASURES: after a change of scene, options or size the first
+	// renders run one candidate each, and from then on the one that traced most rays per millisecond of device time (HIP
+	// events, device ray counters).  Candidates: PT_ENGINE_AUTO -- fused in step, fused out of step (pt_hip.h
+	// PT_FRAME_OUT_OF_STEP; scenes without a BVH), wavefront; PT_ENGINE_FUSED -- its two forms; PT_ENGINE_WAVEFRONT -- none.
+	// A camera restart keeps the decision.
+	enum Candidate : uint32_t { CandWavefront = 0, CandFused = 1, CandFusedOutOfStep = 2, kCandidates = 3 };
+	uint32_t _cands[kCandidates] = { CandFused, CandFused, CandFused };
+	uint32_t _nCands = 1, _probeIdx = 0;        // probing while _probeIdx < _nCands (and _nCands > 1)
+	uint32_t _choice = CandFused, _candInFlight = CandFused;
+	double _candRate[kCandidates] = { 0.0, 0.0, 0.0 };     // rays per ms
+	bool Probing() const { return _nCands > 1 && _probeIdx < _nCands; }
+	void _ResetProbe() {
+		_nCands = 0; _probeIdx = 0;
+		for (double& r : _candRate) r = 0.0;
+		if (_opt.engine == PT_ENGINE_WAVEFRONT) _cands[_nCands++] = CandWavefront;
+		else {
+			_cands[_nCands++] = CandFused;
+			if (!_sceneHasBvh) _cands[_nCands++] = CandFusedOutOfStep;
+			if (_opt.engine == PT_ENGINE_AUTO) _cands[_nCands++] = CandWavefront;
+		}
+		_choice = _cands[0];
+	}
 	uint64_t _raysBefore = 0;
 
 public:
@@ -199,7 +215,7 @@ public:
 		}
 		if (pt_hip_stream_synchronize(_stream) != PT_OK) { _error = hip_layer_fail(PT_ERR_HIP, "FinalizeDrawing"); return; }
 		_frameNumber += _inFlightSamples;
-		if (_inFlightSamples && _opt.engine == PT_ENGINE_AUTO && _autoPhase != Decided) _error = _AutoRecord(ms);
+		if (_inFlightSamples && Probing()) _error = _AutoRecord(ms);
 		_inFlightSamples = 0;
 	}
 
@@ -211,7 +227,7 @@ public:
 		_height = pixelHeight;
 		_camera.Resize(pixelWidth, pixelHeight);
 		_opt.pixel_first = 0; _opt.pixel_count = 0;     // a tile of the old image means nothing now (a TILE split derives its own)
-		_autoPhase = ProbeFused;
+		_ResetProbe();
 		if ((_error = _AllocateDrawingMemory())) return;
 		_error = _InitializeRendering();
 	}
@@ -273,7 +289,7 @@ public:
 		if (_opt.split_mode == PT_SPLIT_NONE) { _opt.split_rank = 0; _opt.split_ranks = 1; }
 		if (_opt.split_ranks == 0) _opt.split_ranks = 1;
 		if (_opt.virtual_shards == 0) _opt.virtual_shards = PT_VIRTUAL_SHARDS;
-		_autoPhase = ProbeFused;
+		_ResetProbe();
 		if (realloc) { if ((_error = _AllocateDrawingMemory())) return _error; }
 		return _error = _InitializeRendering();
 	}
@@ -297,7 +313,7 @@ public:
 		_dev.scene = fresh; _nTris = nt; _nMats = nm; _sceneHasBvh = has_bvh != 0;
 		_sceneHash = 1469598103934665603ull;
 		for (unsigned char c : blob) _sceneHash = (_sceneHash ^ c) * 1099511628211ull;
-		_autoPhase = ProbeFused;
+		_ResetProbe();
 		return _error = _InitializeRendering();
 	}
 
@@ -381,8 +397,10 @@ public:
 		out->frames = _frameNumber;
 		for (int b = 0; b < PT_MAX_DEPTH; b++) out->rays_per_bounce[b] = words[4 + b];
 		out->last_render_ms = _lastMs; out->total_render_ms = _totalMs; out->renders = _renders;
-		out->engine_in_use = _opt.engine != PT_ENGINE_AUTO ? _opt.engine : _autoPhase == Decided ? _autoChoice : (uint32_t)PT_ENGINE_AUTO;
-		out->auto_rays_per_ms[0] = _autoRate[0]; out->auto_rays_per_ms[1] = _autoRate[1];
+		out->engine_in_use = _opt.engine != PT_ENGINE_AUTO ? _opt.engine : Probing() ? (uint32_t)PT_ENGINE_AUTO : _choice == CandWavefront ? (uint32_t)PT_ENGINE_WAVEFRONT : (uint32_t)PT_ENGINE_FUSED;
+		out->fused_out_of_step = !Probing() && _choice == CandFusedOutOfStep ? 1u : 0u;
+		out->auto_rays_per_ms[0] = _candRate[CandWavefront]; out->auto_rays_per_ms[1] = _candRate[CandFused];
+		out->fused_out_of_step_rays_per_ms = _candRate[CandFusedOutOfStep];
 		return PT_OK;
 	}
 	void Size(int* w, int* h, uint32_t* first, uint32_t* count) const {
@@ -613,28 +631,34 @@ private:
 		return PT_OK;
 	}
 
-	// FinalizeDrawing of a probe render: device time and rays of the engine that just ran
+	// FinalizeDrawing of a probe render: device time and rays of the candidate that just ran
 	int _AutoRecord(float ms) {
 		uint64_t rays = 0;
 		if (int rc = _ReadRays(&rays)) return rc;
-		double rate = ms > 0.0f ? (double)(rays - _raysBefore) / ms : 0.0;
-		_autoRate[_engineInFlight] = rate;
-		if (_autoPhase == ProbeFused) _autoPhase = ProbeWavefront;
-		else {
-			_autoChoice = _autoRate[PT_ENGINE_WAVEFRONT] > _autoRate[PT_ENGINE_FUSED] ? PT_ENGINE_WAVEFRONT : PT_ENGINE_FUSED;
-			_autoPhase = Decided;
-			if (_autoChoice == PT_ENGINE_FUSED) { pt_hip_free(_dev.workspace); _dev.workspace = nullptr; _workspaceBytes = 0; }
-		}
+		_candRate[_candInFlight] = ms > 0.0f ? (double)(rays - _raysBefore) / ms : 0.0;
+		if (++_probeIdx < _nCands) return PT_OK;
+		_choice = _cands[0];
+		for (uint32_t k = 1; k < _nCands; k++)
+			if (_candRate[_cands[k]] > _candRate[_choice]) _choice = _cands[k];
+		if (_choice != CandWavefront && _opt.engine == PT_ENGINE_AUTO) { pt_hip_free(_dev.workspace); _dev.workspace = nullptr; _workspaceBytes = 0; }
 		return PT_OK;
 	}
 
-	uint32_t _PickEngine() {
-		if (_opt.engine != PT_ENGINE_AUTO) return _opt.engine;
-		if (_autoPhase == Decided) return _autoChoice;
-		uint32_t e = _autoPhase == ProbeFused ? PT_ENGINE_FUSED : PT_ENGINE_WAVEFRONT;
-		// the wavefront probe needs its queues; if they cannot be had the fused engine stays
-		if (e == PT_ENGINE_WAVEFRONT && _EnsureWorkspace() != PT_OK) { _autoChoice = PT_ENGINE_FUSED; _autoPhase = Decided; return PT_ENGINE_FUSED; }
-		return e;
+	uint32_t _PickCandidate() {
+		if (!Probing()) return _choice;
+		uint32_t c = _cands[_probeIdx];
+		// the wavefront probe needs its queues; if they cannot be had under AUTO it leaves the list (it is the last entry)
+		if (c == CandWavefront && _opt.engine == PT_ENGINE_AUTO && _EnsureWorkspace() != PT_OK) {
+			_nCands--;
+			if (!Probing()) {
+				_choice = _cands[0];
+				for (uint32_t k = 1; k < _nCands; k++)
+					if (_candRate[_cands[k]] > _candRate[_choice]) _choice = _cands[k];
+				return _choice;
+			}
+			c = _cands[_probeIdx];
+		}
+		return c;
 	}
 
 	// PathTracer.cu:116-157, for `samples` samples (SAMPLE split: for each of this instance's shards)
@@ -643,11 +667,13 @@ private:
 		if ((uint64_t)_frameNumber + samples > 0xFFFFFFFFull) return plugin_fail(PT_ERR_LIMIT, "frame counter would overflow");
 		if (SampleSplit() && (uint64_t)_frameNumber + samples > PT_SHARD_SPAN) return plugin_fail(PT_ERR_LIMIT, "sample split: more than PT_SHARD_SPAN samples per shard");
 		pt_frame f = _Frame();
-		uint32_t engine = _PickEngine();
-		if (_opt.engine == PT_ENGINE_AUTO && _autoPhase != Decided) {
+		const uint32_t cand = _PickCandidate();
+		const uint32_t engine = cand == CandWavefront ? (uint32_t)PT_ENGINE_WAVEFRONT : (uint32_t)PT_ENGINE_FUSED;
+		if (cand == CandFusedOutOfStep) f.flags |= PT_FRAME_OUT_OF_STEP;
+		if (Probing()) {
 			if (int rc = _ReadRays(&_raysBefore)) return rc;          // (waits for what is on the stream: probes only)
 		}
-		_engineInFlight = engine;
+		_candInFlight = cand;
 		_imageCurrent = false;
 		PT_TRY(pt_hip_event_record(_evStart, _stream));
 		for (uint32_t j = 0; j < _localShards; j++) {

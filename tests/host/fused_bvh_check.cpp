@@ -1,4 +1,5 @@
-// The fused engine's BVH form on the CPU: fused_bvh_block (pt_fused_bvh.hpp, what k_fused_bvh runs) executed block by block,
+// The fused engine's wave-level forms on the CPU.  Scenes without a BVH: fused_samples_out_of_step (k_fused<*, *, true>), a wave of
+// 64 host threads per 64 pixels.  BVH scenes: fused_bvh_block (pt_fused_bvh.hpp, what k_fused_bvh runs) executed block by block,
 // each block as 256 host threads in four waves of 64 through tests/host/hip_shim -- the persistent walk, the service of
 // finished rays at a quorum, pixels handed out from the block's LDS counter, walks that start at a leaf (path lists) all
 // run as on the device.  Arrays have exactly the size the library gives them, LDS stand-ins start from garbage.
@@ -44,7 +45,8 @@ int main(int argc, char** argv) {
 	unsigned char* blob = (unsigned char*)std::malloc(blob_v.size());
 	std::memcpy(blob, blob_v.data(), blob_v.size());
 	const SceneHeader* hdr = reinterpret_cast<const SceneHeader*>(blob);
-	if (hdr->magic != kSceneMagic || hdr->blob_bytes != blob_v.size() || hdr->n_nodes == 0) { std::fprintf(stderr, "not a BVH scene blob\n"); return 2; }
+	if (hdr->magic != kSceneMagic || hdr->blob_bytes != blob_v.size()) { std::fprintf(stderr, "not a scene blob\n"); return 2; }
+	const bool brute_force = hdr->n_nodes == 0;          // no BVH: the out-of-step form of k_fused (fused_samples_out_of_step), wave by wave
 	const FrameDev f = to_dev(fr);
 	const bool strided = fr.rng_mode == PT_RNG_STRIDED;
 	const uint32_t N = f.pixel_count, n_tris = hdr->n_tris, n_mats = hdr->n_mats;
@@ -59,8 +61,48 @@ int main(int argc, char** argv) {
 	for (uint32_t k = 0; k < 1024u; k++) s_jump[k] = (&jump31.t[0][0])[k];
 	for (uint32_t b = 0; b < 32; b++) { s_first[b] = steps(1u << b, (unsigned long long)frame_first * f.stride); s_per[b] = steps(1u << b, f.stride); }
 	const float4* tris = reinterpret_cast<const float4*>(blob + sizeof(SceneHeader));
-	const BvhView bv = make_bvh_view(blob, n_tris, n_mats, f.origin);
 	unsigned long long rays = 0, diffuse = 0;
+	if (brute_force) {
+		// k_fused<*, *, true>: a block per 256 pixels, a lane per pixel; the camera-ray records as stage_primary_records makes them
+		const bool use_prim = n_tris <= 1024;                                        // kPrimMaxTris (pt_kernels.hip)
+		float4* prim = exact<float4>((size_t)2 * n_tris);
+		for (unsigned t = 0; t < 256; t++) { threadIdx.x = t; stage_primary_records(tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, prim); }
+		const bool det_bounded = (hdr->flags & kSceneDetBounded) != 0;
+		const uint32_t chunks = (N + 255u) / 256u;
+		for (uint32_t blk = 0; blk < chunks; blk++) {
+			WaveShim waves[4];
+			for (auto& w : waves) w.lanes = 64;
+			std::vector<unsigned long long> cnt(256 * 2, 0);
+			std::vector<std::thread> th;
+			for (unsigned t = 0; t < 256; t++)
+				th.emplace_back([&, t] {
+					threadIdx.x = t;
+					t_wave = &waves[t / 64];
+					const uint32_t li = blk * 256u + t;
+					const bool in_range = li < N;
+					const uint32_t i = f.pixel_first + (in_range ? li : 0u);
+					uint32_t start = in_range ? rng[li] : 0u;
+					if (strided) start = mat_apply_lds(s_first, start);
+					uint32_t r = start, n_rays = 0, n_diffuse = 0;
+					float4 m = in_range ? mean[li] : float4{ 0, 0, 0, 0 };
+					FusedLdsCtx c{ f, tris, tris + (size_t)n_tris * 4, use_prim ? prim : nullptr, s_jump, s_per, n_tris, det_bounded, mean_first, n_samples };
+					if (strided) fused_samples_out_of_step<true>(c, in_range, i % (uint32_t)f.width, i / (uint32_t)f.width, start, r, m, n_rays, n_diffuse);
+					else fused_samples_out_of_step<false>(c, in_range, i % (uint32_t)f.width, i / (uint32_t)f.width, start, r, m, n_rays, n_diffuse);
+					if (in_range) { mean[li] = m; if (!strided) rng[li] = r; }
+					cnt[2 * t] = n_rays; cnt[2 * t + 1] = n_diffuse;
+				});
+			for (auto& t : th) t.join();
+			for (unsigned t = 0; t < 256; t++) { rays += cnt[2 * t]; diffuse += cnt[2 * t + 1]; }
+		}
+		FILE* out = std::fopen(argv[7], "wb");
+		if (!out) { std::perror(argv[7]); return 2; }
+		std::fwrite(mean, sizeof(float4), N, out);
+		std::fwrite(rng, sizeof(uint32_t), N, out);
+		std::fclose(out);
+		std::printf("pixels %u samples %u rays %llu diffuse %llu blocks %u\n", N, n_samples, rays, diffuse, chunks);
+		return 0;
+	}
+	const BvhView bv = make_bvh_view(blob, n_tris, n_mats, f.origin);
 	const uint32_t G = (N + range - 1) / range;
 	gridDim.x = G;
 	for (uint32_t blk = 0; blk < G; blk++) {

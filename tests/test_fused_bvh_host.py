@@ -76,3 +76,22 @@ def test_extended_shading_and_a_soup(pt, oracle, tmp_path):
     ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp), scene=oracle.make_scene(V, T, M))
     img, rng, rays = run(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth)
     assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
+
+
+@needs_binary
+@pytest.mark.parametrize("scene,w,h,spp,depth,shading,strided", [("default", 50, 30, 3, 10, 0, False), ("materials", 45, 27, 4, 16, 0, False),
+                                                                 ("mirror", 40, 25, 3, 12, 1, False), ("materials", 37, 23, 3, 8, 0, True),
+                                                                 ("synthetic300", 24, 16, 2, 10, 0, False)])
+def test_brute_force_scenes_out_of_step(pt, oracle, tmp_path, scene, w, h, spp, depth, shading, strided):
+    """fused_samples_out_of_step (k_fused<*, *, true>, PT_FRAME_OUT_OF_STEP): a wave's 64 pixels take their samples out of step;
+    image, streams and ray counts are the oracle's.  A ragged last wave (pixel counts that are no multiple of 64)."""
+    V, T, M = {"default": scenes.default_scene, "materials": scenes.all_materials_scene, "mirror": scenes.mirror_scene,
+               "synthetic300": lambda: scenes.synthetic_scene(300)}[scene]()
+    stride = 2 + (2 if shading else 33) * depth
+    okw = dict(rng_mode=oracle.RNG_STRIDED, stride=stride, frame_first=2) if strided else {}
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, shading=shading, **okw), scene=oracle.make_scene(V, T, M))
+    kw = dict(rng_mode=1, stride=stride, frame_first=2, mean_first=2) if strided else {}
+    img, rng, rays = run(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, shading=shading, **kw)
+    assert np.array_equal(bits(img), bits(ref)) and rays == st.rays
+    if not strided:
+        assert np.array_equal(rng, ref_rng)

@@ -617,3 +617,34 @@ def test_fused_engine_on_bvh_scenes_persistent_and_plain_forms_agree(pt, oracle,
         assert st.rays == st_ref.rays and st.diffuse_bounces * 33 + st.paths * 2 == st_ref.draws
         if not strided:
             assert np.array_equal(rng, ref_rng)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,spp,depth,shading,strided", [("default", 333, 187, 5, 10, 0, False), ("materials", 200, 120, 6, 16, 0, False),
+                                                                 ("mirror", 160, 90, 4, 16, 1, False), ("materials", 128, 72, 6, 12, 0, True),
+                                                                 ("synthetic300", 96, 54, 3, 10, 0, False), ("soup", 96, 60, 3, 8, 0, False)])
+def test_fused_engine_out_of_step_form(pt, oracle, scene, w, h, spp, depth, shading, strided):
+    """k_fused<*, *, true> (PT_FRAME_OUT_OF_STEP; forced for every render here through the environment knob): the pixels of a wave
+    take their samples out of step.  Image, streams, ray and draw counts are the oracle's on every scene kind without a BVH."""
+    import os
+    V, T, M = {"default": scenes.default_scene, "materials": scenes.all_materials_scene, "mirror": scenes.mirror_scene,
+               "synthetic300": lambda: scenes.synthetic_scene(300), "soup": lambda: scenes.triangle_soup(60, 3)}[scene]()
+    stride = 2 + (2 if shading else 33) * depth
+    okw = dict(rng_mode=oracle.RNG_STRIDED, stride=stride) if strided else {}
+    kw = dict(rng_mode=pt.PT_RNG_STRIDED, stride=stride) if strided else {}
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, shading=shading, **okw), scene=oracle.make_scene(V, T, M))
+    os.environ["PT_FUSED_OUT_OF_STEP"] = "1"
+    try:
+        with pt.PathTracer(w, h) as tr:
+            tr.set_scene(*pt.make_scene(V, T, M))
+            tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth, shading=shading, **kw)
+            tr.render(1)
+            tr.render(spp - 1)
+            img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+    finally:
+        os.environ.pop("PT_FUSED_OUT_OF_STEP", None)
+    diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+    assert not diff.any(), f"{int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+    assert st.rays == st_ref.rays
+    if not strided:
+        assert np.array_equal(rng, ref_rng)

@@ -157,21 +157,35 @@ def test_cpp_multi_gpu_host(pt, oracle, tmp_path, instances, mode):
 
 @pytest.mark.parametrize("scene_name", ["default", "materials", "synthetic2500"])
 def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
-    """PT_ENGINE_AUTO (the default): first render fused, second wavefront, then the faster of the two -- the image is the
-    oracle's whichever runs, and a camera restart keeps the decision"""
+    """PT_ENGINE_AUTO (the default): the first renders measure one candidate each -- fused in step, fused out of step (scenes
+    without a BVH), wavefront -- then the fastest stays; the image is the oracle's whichever runs, and a camera restart keeps
+    the decision"""
     V, T, M = {"default": scenes.default_scene, "materials": scenes.all_materials_scene, "synthetic2500": lambda: scenes.synthetic_scene(2500)}[scene_name]()
     w, h = 200, 120
     ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=7), scene=oracle.make_scene(V, T, M))
+    has_bvh = len(T) > 512
     with pt.PathTracer(w, h) as tr:
         assert tr.get_options().engine == pt.PT_ENGINE_AUTO
         tr.set_scene(*pt.make_scene(V, T, M))
         assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO
-        tr.render(3)
-        tr.render(3)
+        tr.render(2)
+        tr.render(2)
+        if has_bvh:
+            tr.render(2)                                      # two candidates: decided after the second render
+        else:
+            assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO          # three candidates: still measuring
+            tr.render(2)
         st = tr.stats()
         assert st.engine_in_use in (pt.PT_ENGINE_FUSED, pt.PT_ENGINE_WAVEFRONT)
-        assert st.auto_rays_per_ms[0] > 0 and st.auto_rays_per_ms[1] > 0
-        assert st.engine_in_use == (pt.PT_ENGINE_WAVEFRONT if st.auto_rays_per_ms[0] > st.auto_rays_per_ms[1] else pt.PT_ENGINE_FUSED)
+        rates = {"wavefront": st.auto_rays_per_ms[0], "fused": st.auto_rays_per_ms[1]}
+        if not has_bvh:
+            rates["fused out of step"] = st.fused_out_of_step_rays_per_ms
+        else:
+            assert st.fused_out_of_step_rays_per_ms == 0 and st.fused_out_of_step == 0
+        assert all(v > 0 for v in rates.values()), rates
+        best = max(rates, key=rates.get)
+        assert st.engine_in_use == (pt.PT_ENGINE_WAVEFRONT if best == "wavefront" else pt.PT_ENGINE_FUSED)
+        assert st.fused_out_of_step == (1 if best == "fused out of step" else 0)
         tr.render(1)
         img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
         assert_bit_equal(img, ref, f"auto on {scene_name}")

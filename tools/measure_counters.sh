@@ -7,7 +7,7 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-STEPS=3; WARM=1
+STEPS=8; WARM=1; SETTLE=3      # bench.py renders SETTLE untimed steps first (the plugin measures its candidates there)
 for wl in default c5 c4_10k; do
   for eng in fused wavefront; do
     i=0
@@ -18,4 +18,4 @@ for wl in default c5 c4_10k; do
     done
   done
 done
-python3 tools/counters_to_json.py $OUT $((STEPS+WARM)) > $OUT/traffic.json && echo counters_done
+python3 tools/counters_to_json.py $OUT $((STEPS+WARM+SETTLE)) > $OUT/traffic.json && echo counters_done
