@@ -126,7 +126,7 @@ class PathTracer final : public IPathTracer {
 	double _candRate[kCandidates] = { 0.0, 0.0, 0.0 };     // rays per ms
 	bool Probing() const { return _nCands > 1 && _probeIdx < _nCands; }
 	void _ResetProbe() {
-		_nCands = 0; _probeIdx = 0;
+		_nCands = 0; _probeIdx = 0; _probedSamples = 0;
 		for (double& r : _candRate) r = 0.0;
 		if (_opt.engine == PT_ENGINE_WAVEFRONT) _cands[_nCands++] = CandWavefront;
 		else {
@@ -137,6 +137,7 @@ class PathTracer final : public IPathTracer {
 		_choice = _cands[0];
 	}
 	uint64_t _raysBefore = 0;
+	uint32_t _probedSamples = 0;        // samples per render the candidates were measured at (0: not yet)
 
 public:
 	PathTracer(int pixelWidth, int pixelHeight, const CameraData* cameraData)
@@ -667,6 +668,13 @@ private:
 		if ((uint64_t)_frameNumber + samples > 0xFFFFFFFFull) return plugin_fail(PT_ERR_LIMIT, "frame counter would overflow");
 		if (SampleSplit() && (uint64_t)_frameNumber + samples > PT_SHARD_SPAN) return plugin_fail(PT_ERR_LIMIT, "sample split: more than PT_SHARD_SPAN samples per shard");
 		pt_frame f = _Frame();
+		// the candidates' order depends on the samples per call (out of step and the persistent forms gain with them): a host
+		// that starts batching much more, or much less, than when they were measured gets them measured again
+		if (_nCands > 1 && !Probing() && _probedSamples != 0u && (samples >= 4u * _probedSamples || 4u * samples <= _probedSamples)) {
+			_probeIdx = 0;
+			for (double& r : _candRate) r = 0.0;
+		}
+		if (Probing() && _probeIdx == 0) _probedSamples = samples;
 		const uint32_t cand = _PickCandidate();
 		const uint32_t engine = cand == CandWavefront ? (uint32_t)PT_ENGINE_WAVEFRONT : (uint32_t)PT_ENGINE_FUSED;
 		if (cand == CandFusedOutOfStep) f.flags |= PT_FRAME_OUT_OF_STEP;

@@ -197,3 +197,29 @@ def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
         img2 = tr.readback()
     ref2, _, _, _ = oracle.render(oracle.params(w, h, cam=oracle.make_camera(fov=80.0), spp=2), scene=oracle.make_scene(V, T, M))
     assert_bit_equal(img2, ref2, f"auto on {scene_name} after a camera restart")
+
+
+def test_candidates_are_measured_again_when_the_samples_per_call_change(pt, oracle):
+    """the fastest kernels at one sample per call need not be the fastest at 64: a fourfold change of the samples per render
+    starts the measurement over (the image stays the oracle's throughout)"""
+    V, T, M = scenes.all_materials_scene()
+    w, h = 160, 90
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=12)
+        for _ in range(3):
+            tr.render(1)
+        first = tr.stats()
+        assert first.auto_rays_per_ms[1] > 0 and first.fused_out_of_step_rays_per_ms > 0       # both forms measured at 1 sample per call
+        tr.render(2)                                       # not a fourfold change: nothing is measured again
+        assert tr.stats().auto_rays_per_ms[1] == first.auto_rays_per_ms[1]
+        tr.render(16)                                      # measured again: in step first ...
+        mid = tr.stats()
+        assert mid.auto_rays_per_ms[1] != first.auto_rays_per_ms[1] and mid.fused_out_of_step_rays_per_ms == 0
+        tr.render(16)                                      # ... then out of step
+        last = tr.stats()
+        assert last.fused_out_of_step_rays_per_ms > 0
+        assert last.fused_out_of_step == (1 if last.fused_out_of_step_rays_per_ms > last.auto_rays_per_ms[1] else 0)
+        img = tr.readback()
+    ref, _, _, _ = oracle.render(oracle.params(w, h, depth=12, spp=3 + 2 + 32), scene=oracle.make_scene(V, T, M))
+    assert_bit_equal(img, ref, "all materials, fused engine across two measurements")
