@@ -42,7 +42,7 @@ bool parse_size(const char* s, int& w, int& h) { return std::sscanf(s, "%dx%d", 
 int main(int argc, char** argv) {
 	std::string plugin = "PT_HipWavefront", scene, out, engine, shading, resume, checkpoint;
 	int width = 960, height = 540;                           // the reference's window, main.cpp:5
-	int frames = 64, sppPerFrame = 1, depth = 0, moveAt = -1, resizeAt = -1, newW = 0, newH = 0, reportEvery = 0;
+	int frames = 64, sppPerFrame = 1, depth = 0, moveAt = -1, resizeAt = -1, newW = 0, newH = 0, reportEvery = 0, snapshotEvery = 0;
 	CameraData* cameraData = new CameraData();               // Program.cpp:36
 	for (int a = 1; a < argc; a++) {
 		auto need = [&](int n) { if (a + n >= argc) { std::fprintf(stderr, "%s needs %d argument(s)\n", argv[a], n); std::exit(2); } };
@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
 		else if (!std::strcmp(argv[a], "--resize-at")) { need(2); resizeAt = std::atoi(argv[++a]); if (!parse_size(argv[++a], newW, newH)) { std::fprintf(stderr, "bad --resize-at\n"); return 2; } }
 		else if (!std::strcmp(argv[a], "--report-every")) { need(1); reportEvery = std::atoi(argv[++a]); }
 		else if (!std::strcmp(argv[a], "--out")) { need(1); out = argv[++a]; }
+		else if (!std::strcmp(argv[a], "--snapshot-every")) { need(1); snapshotEvery = std::atoi(argv[++a]); }   // with --out: <out>.<frame>.pfm every N frames (a progressive display's periodic readback)
 		else if (!std::strcmp(argv[a], "--resume")) { need(1); resume = argv[++a]; }               // pt_load_state before the first frame
 		else if (!std::strcmp(argv[a], "--checkpoint")) { need(1); checkpoint = argv[++a]; }       // pt_save_state after the last frame
 		else { std::fprintf(stderr, "unknown argument %s\n", argv[a]); return 2; }
@@ -112,6 +113,13 @@ int main(int argc, char** argv) {
 		pathTracer->Update(cameraData);        // Program.cpp:58
 		pathTracer->FinalizeDrawing();         // Program.cpp:70
 		framesSinceReport++;
+		if (snapshotEvery > 0 && !out.empty() && readback && (frame + 1) % snapshotEvery == 0 && frame + 1 < frames) {
+			std::vector<float> rgba((size_t)width * height * 4);
+			std::string name = out + "." + std::to_string(frame + 1) + ".pfm";
+			if (readback(pathTracer, rgba.data(), rgba.size())) return fail("pt_readback");
+			if (!write_pfm(name.c_str(), rgba, width, height)) { std::fprintf(stderr, "cannot write %s\n", name.c_str()); return 6; }
+			std::printf("wrote %s\n", name.c_str());
+		}
 		if (reportEvery > 0 && framesSinceReport == reportEvery) {
 			auto now = std::chrono::steady_clock::now();
 			double ms = std::chrono::duration<double, std::milli>(now - tReport).count() / framesSinceReport;

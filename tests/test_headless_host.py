@@ -111,3 +111,18 @@ def test_hip_plugin_checkpoint_and_resume_across_processes(oracle, tmp_path):
     # the CPU-oracle plugin has no state files: the host says so instead of crashing
     r = run_host("--plugin", CPU_PLUGIN, "--frames", 1, "--checkpoint", tmp_path / "x.bin")
     assert r.returncode == 5 and "not exported" in r.stderr
+
+
+def test_periodic_snapshots_are_the_running_mean_so_far(oracle, tmp_path):
+    """--snapshot-every N: the periodic readback of a progressive display (Program.cpp draws the texture every frame); snapshot k
+    is the k-sample image, the final one the full image"""
+    out = tmp_path / "prog.pfm"
+    r = run_host("--plugin", CPU_PLUGIN, "--size", "48x32", "--frames", 5, "--snapshot-every", 2, "--out", out)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in (2, 4):
+        img, w, h = read_pfm(f"{out}.{k}.pfm")
+        ref, _, _, _ = oracle.render(oracle.params(48, 32, spp=k))
+        assert (w, h) == (48, 32) and np.array_equal(bits(img), bits(ref[:, :3])), k
+    img, _, _ = read_pfm(out)
+    ref, _, _, _ = oracle.render(oracle.params(48, 32, spp=5))
+    assert np.array_equal(bits(img), bits(ref[:, :3]))
