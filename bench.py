@@ -52,7 +52,7 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 P_LIGHT = 0.0473
 BYTES_PER_RAY = (276.0 + 44.0 * P_LIGHT) / 2.0
 KERNEL_SOURCES = ["pathtracer_amd/csrc/pt_kernels.hip", "pathtracer_amd/csrc/pt_device.hpp", "pathtracer_amd/csrc/pt_wavefront.hpp",
-                  "pathtracer_amd/csrc/pt_bvh.hpp"]
+                  "pathtracer_amd/csrc/pt_fused_bvh.hpp", "pathtracer_amd/csrc/pt_bvh.hpp"]
 
 # name -> (scene, depth, stride of the strided streams, description)
 WORKLOADS = {
@@ -178,7 +178,7 @@ def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples
         tracer.set_options(engine=eng, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=samples_per_pass)
     # the plugin measures its candidates (fused in step / out of step, wavefront under AUTO) on the first renders after a
     # restart: those come first, untimed and on top of the W warm-up steps, so that the timed steps run the decided kernels
-    settle = 3
+    settle = 4
     for _ in range(settle + warmup):
         tracer.render(spp)
     st0 = tracer.stats()
@@ -388,7 +388,7 @@ def main():
 
     if not native:
         exchanged.record(exchange_stream)
-    for k in range(args.warmup):
+    for k in range(4 + args.warmup):                              # 4: the plugin measures its candidates on the first renders (untimed)
         step(k)
     exchange()                                                    # warm the collectives up too
     sync()

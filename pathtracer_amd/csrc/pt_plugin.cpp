@@ -115,18 +115,19 @@ class PathTracer final : public IPathTracer {
 	// against 222 Grays/s; all materials at depth 16: the fused engine out of step 29 against 16 in step; BVH scenes under
 	// the reference's streams: fused 8.5 against 5.7, with strided batches the wavefront engine 10.7; at 64x40 the staged
 	// pipeline's 30 launches per sample lose).  So the plugin MEASURES: after a change of scene, options or size the first
-	// renders run one candidate each, and from then on the one that traced most rays per millisecond of device time (HIP
-	// events, device ray counters).  Candidates: PT_ENGINE_AUTO -- fused in step, fused out of step (pt_hip.h
+	// renders run one candidate each (after one unmeasured render: a cold device would count against whoever goes first), and
+	// from then on the one that traced most rays per millisecond of device time (HIP events, device ray counters).  Candidates: PT_ENGINE_AUTO -- fused in step, fused out of step (pt_hip.h
 	// PT_FRAME_OUT_OF_STEP; scenes without a BVH), wavefront; PT_ENGINE_FUSED -- its two forms; PT_ENGINE_WAVEFRONT -- none.
 	// A camera restart keeps the decision.
 	enum Candidate : uint32_t { CandWavefront = 0, CandFused = 1, CandFusedOutOfStep = 2, kCandidates = 3 };
 	uint32_t _cands[kCandidates] = { CandFused, CandFused, CandFused };
 	uint32_t _nCands = 1, _probeIdx = 0;        // probing while _probeIdx < _nCands (and _nCands > 1)
+	bool _probeWarm = false;                    // the first render after a (re)start has run: it is not measured (cold caches, first touch of fresh buffers)
 	uint32_t _choice = CandFused, _candInFlight = CandFused;
 	double _candRate[kCandidates] = { 0.0, 0.0, 0.0 };     // rays per ms
 	bool Probing() const { return _nCands > 1 && _probeIdx < _nCands; }
 	void _ResetProbe() {
-		_nCands = 0; _probeIdx = 0; _probedSamples = 0;
+		_nCands = 0; _probeIdx = 0; _probedSamples = 0; _probeWarm = false;
 		for (double& r : _candRate) r = 0.0;
 		if (_opt.engine == PT_ENGINE_WAVEFRONT) _cands[_nCands++] = CandWavefront;
 		else {
@@ -636,6 +637,7 @@ private:
 	int _AutoRecord(float ms) {
 		uint64_t rays = 0;
 		if (int rc = _ReadRays(&rays)) return rc;
+		if (!_probeWarm) { _probeWarm = true; return PT_OK; }       // the very first render only warms the device up: the first candidate runs again
 		_candRate[_candInFlight] = ms > 0.0f ? (double)(rays - _raysBefore) / ms : 0.0;
 		if (++_probeIdx < _nCands) return PT_OK;
 		_choice = _cands[0];

@@ -7,7 +7,7 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-STEPS=8; WARM=1; SETTLE=3      # bench.py renders SETTLE untimed steps first (the plugin measures its candidates there)
+STEPS=8; WARM=1; SETTLE=4      # bench.py renders SETTLE untimed steps first (the plugin measures its candidates there)
 for wl in default c5 c4_10k; do
   for eng in fused wavefront; do
     i=0
