@@ -311,6 +311,38 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 	if (threadIdx.x == 0) count_out[blockIdx.x] = s_out;
 }
 
+// BVH scenes: the rays of bounce `entry_bounce` and every bounce after them in one persistent launch (pt_wavefront.hpp,
+// bounce_tail_block).  counts: row entry_bounce = the block's queue entries (read), rows above it = the rays of the later bounces (written).
+#ifndef PT_TAIL_WAVES
+#define PT_TAIL_WAVES 6
+#endif
+#ifndef PT_TAIL_ENTRY
+#define PT_TAIL_ENTRY 2
+#endif
+constexpr uint32_t kTailEntryBounce = PT_TAIL_ENTRY;      // the bounce whose hits the persistent tail starts from
+__global__ __launch_bounds__(kBlock, PT_TAIL_WAVES) void k_bounce_tail(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
+                                                           uint32_t entry_bounce,
+                                                           const float4* __restrict__ qa, const float4* __restrict__ qb, const float4* __restrict__ qc,
+                                                           const uint32_t* __restrict__ qpid,
+                                                           uint32_t* __restrict__ counts, uint32_t capacity,
+                                                           float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out) {
+	extern __shared__ float4 s_dyn[];
+	uint32_t* s_stack = reinterpret_cast<uint32_t*>(s_dyn);
+	__shared__ uint32_t s_jump[1024];
+	__shared__ uint32_t s_next, s_count[PT_MAX_DEPTH + 1];
+	stage_jump31(s_jump);
+	if (threadIdx.x == 0) s_next = 0;
+	if (threadIdx.x <= PT_MAX_DEPTH) s_count[threadIdx.x] = 0;
+	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
+	const float4* mats = tris + (size_t)n_tris * 4;
+	const BvhView bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
+	__syncthreads();
+	ShadeCtx c{ f, tris, mats, s_jump, n_tris, scene_det_bounded(scene), capacity, radiance, lit, rng_out, nullptr, nullptr };
+	bounce_tail_block(c, bv, entry_bounce, qa, qb, qc, qpid, counts[(size_t)entry_bounce * gridDim.x + blockIdx.x], s_stack, &s_next, s_count);
+	__syncthreads();
+	if (threadIdx.x > entry_bounce && threadIdx.x <= f.depth) counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_count[threadIdx.x];
+}
+
 // One pass of an LDS-resident scene in ONE launch: stages the block's LDS, then bounces_block (pt_wavefront.hpp).
 template <bool SEQ>
 __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
@@ -1107,6 +1139,24 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 		} else {
 			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
 			if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
+			// BVH scenes: the first bounces staged (camera rays, and the bulk of the bounced ones, each in an extend of its own at full
+			// occupancy, each shade a streaming pass), the RAYS of bounce kTailEntryBounce and everything after them in one persistent launch
+			const char* tail_env = std::getenv("PT_WAVEFRONT_TAIL");             // measurement / test knob: "off" = every bounce staged, a digit = the tail's entry bounce
+			const uint32_t tail_from = !scene_has_bvh(si) || (tail_env && tail_env[0] == 'o') ? 0xFFFFFFFFu : tail_env ? (uint32_t)std::atoi(tail_env) : kTailEntryBounce;
+			if (tail_from >= 1u && tail_from < frame->depth && tail_from < 0xFFFFFFFFu) {
+				for (uint32_t b = 0; b < tail_from; b++) {
+					int in = b & 1, out = in ^ 1;
+					launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
+					pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
+					if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
+					                          nullptr, w.counts + (size_t)(b + 1) * G, w.radiance, w.lit, sequential ? rng : nullptr, s)) return rc;
+				}
+				int in = tail_from & 1;
+				size_t lds = (size_t)bvh_stack_depth(si.n_tris) * kBlock * sizeof(uint32_t);
+				hipLaunchKernelGGL(k_bounce_tail, dim3(G), dim3(kBlock), lds, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, tail_from,
+				                   (const float4*)w.a[in], (const float4*)w.b[in], (const float4*)w.c[in], (const uint32_t*)w.pid[in],
+				                   w.counts, (uint32_t)paths_cap, w.radiance, w.lit, sequential ? rng : nullptr);
+			} else
 			for (uint32_t b = 0; b < frame->depth; b++) {
 				int in = b & 1, out = in ^ 1;
 				launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);

@@ -410,4 +410,92 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 	}
 }
 
+
+// ---- BVH scenes: the late bounces in ONE persistent kernel (k_bounce_tail) ----
+// The staged pipeline launches extend + shade once per bounce; from the third ray of a path on the queues hold a few per cent
+// of the rays, spread over up to sixty launches that cannot fill the machine.  Here a block takes the RAYS of its own queue
+// slots at bounce `entry_bounce` (the shade stage before wrote them) and a path stays IN ITS LANE from there: walked
+// (bvh_round, the while-while walk of the extend stage), shaded from registers (the same shade_lane as k_shade), the
+// bounce ray set up and walked, and so on to its end, while lanes whose path has ended take the block's next queue entry
+// (one LDS counter per block).  No queue is written any more.  counts[b][block] (b > entry_bounce) receive the rays of
+// bounce b, as the staged shade stages would have left them, for k_fold_counts.
+// Measured, 1080p, 10 092 / 99 372 triangles, strided batches of 16: every bounce staged 10.74 / 8.83 Grays/s; this tail
+// from the rays of bounce 2: 10.88 / 9.22 (4 samples per pass: 8.94 -> 9.60); from bounce 3: 10.91 / 9.07.  A tail that starts
+// from HITS and shades them itself loses where few of them go on, because a hand-out that ends at its first shade costs a
+// service round with few lanes busy: from the camera rays' hits (six in ten go on) 10.3, from bounce 1's (one in ten) 9.5.
+// *s_next == 0, s_count[0 .. depth] == 0 and a block barrier passed on entry; s_stack: bvh_stack_depth x 256 words.
+#ifndef PT_TAIL_SERVICE
+#define PT_TAIL_SERVICE 32
+#endif
+__device__ __forceinline__ void bounce_tail_block(const ShadeCtx& c, const BvhView& bv, uint32_t entry_bounce,
+                                                  const float4* __restrict__ qa, const float4* __restrict__ qb, const float4* __restrict__ qc,
+                                                  const uint32_t* __restrict__ qpid, uint32_t count,
+                                                  uint32_t* s_stack, uint32_t* s_next, uint32_t* s_count) {
+	const FrameDev& f = c.f;
+	const uint32_t G = gridDim.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t* stack = s_stack + threadIdx.x;
+	const bool extended = f.shading == PT_SHADING_EXTENDED;
+	bool has_path = false, exhausted = false;
+	uint32_t bounce = 0;                 // of the ray the lane is walking
+	PathNext r;                          // the path: origin, direction, throughput, stream, path id
+	float best = 0.0f;
+	uint32_t tri = kNoHit;
+	BvhRay ray{};
+	int32_t cur = kBvhDone;
+	int sp = 0;
+	for (;;) {
+		const bool walking = cur != kBvhDone;
+		const bool waiting = !walking && (has_path || !exhausted);
+		const uint32_t n_waiting = (uint32_t)__popcll(__ballot(waiting));
+		const bool any_walking = __any(walking);
+		if (n_waiting >= (uint32_t)PT_TAIL_SERVICE || (!any_walking && n_waiting != 0u)) {
+			bool fresh = false;
+			if (waiting && has_path) {
+				// the ray of bounce `bounce` is finished: Intersect (kernels.cu:71-94) from registers, laid out as the queue entry would be
+				const float4 la{ r.o.x, r.o.y, r.o.z, r.d.x }, lb{ r.d.y, r.d.z, 0.0f, __uint_as_float(r.rng) }, lc = r.step;
+				PathNext nx;
+				nx.pid = r.pid;
+				const uint32_t last = bounce + 1u >= f.depth ? 1u : 0u;
+				shade_lane<false, false, false, false>(c, extended, last, 0u, uint2{ __float_as_uint(best), tri }, float4{ 0, 0, 0, 0 }, &la, &lb, &lc, nx);
+				if (nx.cont) atomicAdd(&s_count[bounce + 1u], 1u);
+				has_path = nx.cont && !last;
+				if (has_path) { r = nx; bounce++; fresh = true; }
+			}
+			const bool want = waiting && !has_path;
+			const unsigned long long want_mask = __ballot(want);
+			if (want_mask != 0ull && !exhausted) {
+				const uint32_t n_want = (uint32_t)__popcll(want_mask);
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(s_next, n_want);
+				base = __shfl(base, 0, 64);
+				const uint32_t j = base + (uint32_t)__popcll(want_mask & ((1ull << lane) - 1ull));
+				if (base + n_want >= count) exhausted = true;
+				if (want && j < count) {
+					const uint32_t q = ((j / kQueueBlock) * G + blockIdx.x) * kQueueBlock + (j % kQueueBlock);
+					if (q < c.capacity) {
+						const float4 a = qa[q], b = qb[q];
+						r.o = Vec3{ a.x, a.y, a.z }; r.d = Vec3{ a.w, b.x, b.y };
+						r.t = b.z; r.rng = __float_as_uint(b.w);
+						r.step = qc[q]; r.pid = qpid[q];
+						has_path = true; bounce = entry_bounce; fresh = true;
+					}
+				}
+			}
+			if (fresh) {
+				best = r.t;
+				tri = kNoHit;
+				ray = bvh_ray_setup(bv, r.o, r.d, best);
+				cur = 0; sp = 0;
+			}
+		}
+		if (!__any(cur != kBvhDone)) {            // a lane that holds a path walks: nobody walking = no path in flight
+			if (exhausted) break;
+			continue;                             // (hand-outs that found no slot: the counter has advanced, the next service hands out more)
+		}
+		PT_TIME_NULL();
+		bvh_round(bv, ray, r.o, r.d, best, tri, cur, sp, stack PT_TIME_ARG);
+	}
+}
+
 } // namespace ptd

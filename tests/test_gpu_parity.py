@@ -648,3 +648,37 @@ def test_fused_engine_out_of_step_form(pt, oracle, scene, w, h, spp, depth, shad
     assert st.rays == st_ref.rays
     if not strided:
         assert np.array_equal(rng, ref_rng)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shading,depth", [(0, 10), (1, 12), (0, 3)])
+def test_wavefront_bvh_late_bounces_in_one_persistent_launch(pt, oracle, shading, depth):
+    """k_bounce_tail (pt_wavefront.hpp bounce_tail_block): on BVH scenes the rays of bounce 2 and everything after them run in one
+    persistent launch; PT_WAVEFRONT_TAIL=off in the environment keeps every bounce staged.  Both give the oracle's image and the
+    oracle's rays PER BOUNCE (the tail fills the counter rows the staged shade stages would have); depth 3: the shortest path the
+    tail takes, mirrors under extended shading: long ones."""
+    import os
+    V, T, M = scenes.synthetic_scene(2500)
+    if shading:
+        M = [(m[0], m[1], 0.8) for m in M]
+    w, h, spp = 320, 180, 6
+    stride = 2 + (2 if shading else 33) * depth
+    ref, _, st_ref, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, shading=shading, rng_mode=oracle.RNG_STRIDED, stride=stride),
+                                      scene=oracle.make_scene(V, T, M))
+    for tail in ("on", "off"):
+        if tail == "off":
+            os.environ["PT_WAVEFRONT_TAIL"] = "off"
+        try:
+            with pt.PathTracer(w, h) as tr:
+                tr.set_scene(*pt.make_scene(V, T, M))
+                tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT, depth=depth, shading=shading, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=4)
+                tr.render(spp)
+                img, st = tr.readback(), tr.stats()
+        finally:
+            os.environ.pop("PT_WAVEFRONT_TAIL", None)
+        diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+        assert not diff.any(), f"tail {tail}: {int(diff.sum())} pixels differ"
+        assert st.rays == st_ref.rays and list(st.rays_per_bounce) == list(st_ref.rays_per_bounce), tail
+        if not shading:                                   # (extended: mirrors continue without a draw)
+            assert st.diffuse_bounces * 33 + st.paths * 2 == st_ref.draws
+    assert st_ref.rays_per_bounce[2] > 0                  # there ARE late bounces on this scene
