@@ -412,8 +412,8 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 
 
 // ---- BVH scenes: the late bounces in ONE persistent kernel (k_bounce_tail) ----
-// The staged pipeline launches extend + shade once per bounce; from the third ray of a path on the queues hold a few per cent
-// of the rays, spread over up to sixty launches that cannot fill the machine.  Here a block takes the RAYS of its own queue
+// The staged pipeline launches extend + shade once per bounce; from the third ray of a path on the queues hold a fifth of the
+// rays (10 092 triangles: 13 % at bounce 2, 6 % beyond), spread over up to sixty launches that fill the machine less and less.  Here a block takes the RAYS of its own queue
 // slots at bounce `entry_bounce` (the shade stage before wrote them) and a path stays IN ITS LANE from there: walked
 // (bvh_round, the while-while walk of the extend stage), shaded from registers (the same shade_lane as k_shade), the
 // bounce ray set up and walked, and so on to its end, while lanes whose path has ended take the block's next queue entry

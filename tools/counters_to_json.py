@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 root, steps_run = sys.argv[1], int(sys.argv[2])
-RENDER = ("k_fused", "k_bounces", "k_extend", "k_shade", "k_generate", "k_accumulate", "k_fold_counts", "k_set_count", "k_sample_matrices")
+RENDER = ("k_fused", "k_bounces", "k_bounce_tail", "k_extend", "k_shade", "k_generate", "k_accumulate", "k_fold_counts", "k_set_count", "k_sample_matrices")
 entries = {}
 for d in sorted(glob.glob(os.path.join(root, "pmc_*_p*/"))):
     m = re.match(r"pmc_(.+)_(fused|wavefront)_p(\d+)", os.path.basename(d.rstrip("/")))
