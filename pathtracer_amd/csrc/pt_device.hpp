@@ -69,6 +69,16 @@ __device__ __forceinline__ uint32_t byte_jump(const uint32_t* __restrict__ t, ui
 	return t[x & 255u] ^ t[256u + ((x >> 8) & 255u)] ^ t[512u + ((x >> 16) & 255u)] ^ t[768u + (x >> 24)];
 }
 
+// table[j][v] = step^stride(v << 8j) = xor of the columns 8j+i of step^stride over the set bits i of v (all lanes of the
+// block take part; a block barrier must follow before the table is read)
+__device__ __forceinline__ void build_stride_table(const uint32_t* __restrict__ stride_cols, uint32_t* __restrict__ s_stride) {
+	for (uint32_t e = threadIdx.x; e < 1024u; e += blockDim.x) {
+		uint32_t j = e >> 8, v = e & 255u, x = 0;
+		for (uint32_t i = 0; i < 8; i++) x ^= stride_cols[8u * j + i] & (0u - ((v >> i) & 1u));
+		s_stride[e] = x;
+	}
+}
+
 // Branch-free matrix-vector product; `cols` is wave-uniform (scalar loads / LDS broadcast).
 __device__ __forceinline__ uint32_t mat_apply(const uint32_t* __restrict__ cols, uint32_t x) {
 	uint32_t y = 0;

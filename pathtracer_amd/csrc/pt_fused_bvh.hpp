@@ -28,8 +28,8 @@ struct FusedBvhCtx {
 	const float4* tris;                  // TriRec array (normals, material indices)
 	const float4* mats;
 	const uint32_t* s_jump;              // step^31 byte tables (LDS)
-	const volatile uint32_t* s_first;    // STRIDED: step^(frame_first * stride) and step^stride as 32 columns each (LDS)
-	const volatile uint32_t* s_per_sample;
+	const volatile uint32_t* s_first;    // STRIDED: step^(frame_first * stride) as 32 columns (LDS)
+	const uint32_t* s_stride;            // STRIDED: step^stride as a byte table, 1024 words (LDS; build_stride_table)
 	uint32_t mean_first, n_samples;      // n_samples >= 1
 	uint32_t* rng_io;
 	float4* mean_io;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 					// the sample is complete: DrawToTexture (kernels.cu:4-19), then the stream of the next one
 					m = running_mean(frame, m, c.mean_first + s);
 					if (STRIDED) {
-						if (draws != f.stride) rng = mat_apply_lds(c.s_per_sample, start);
+						if (draws != f.stride) rng = byte_jump(c.s_stride, start);
 						start = rng;
 					}
 					s++;
@@ -182,7 +182,7 @@ struct FusedLdsCtx {
 	const float4* mats;
 	const float4* prim;                  // camera-ray records (stage_primary_records), or nullptr: no culled camera intersection
 	const uint32_t* s_jump;
-	const volatile uint32_t* s_per_sample;       // STRIDED: step^stride as 32 columns (LDS)
+	const uint32_t* s_stride;            // STRIDED: step^stride as a byte table, 1024 words (LDS; build_stride_table)
 	uint32_t n_tris;
 	bool det_bounded;
 	uint32_t mean_first, n_samples;
@@ -234,7 +234,7 @@ __device__ __forceinline__ void fused_samples_out_of_step(const FusedLdsCtx& c, 
 		} else {
 			m = running_mean(frame, m, c.mean_first + s);
 			if (STRIDED) {
-				if (draws != f.stride) rng = mat_apply_lds(c.s_per_sample, start);
+				if (draws != f.stride) rng = byte_jump(c.s_stride, start);
 				start = rng;
 			}
 			s++;

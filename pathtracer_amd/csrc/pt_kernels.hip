@@ -456,7 +456,10 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 	// STRIDED: the two jump matrices are read from LDS, not kept in 64 SGPRs across the pixel loop (106 SGPRs admit
 	// 6 blocks per CU, 74 admit 8)
 	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1];
+	// ... and step^stride, taken once per sample whose draws differ from the stride, as a byte table (4 lookups instead of 32 columns)
+	__shared__ uint32_t s_stride[STRIDED ? 1024 : 1];
 	if (STRIDED && threadIdx.x < 32) { s_first[threadIdx.x] = first.cols[threadIdx.x]; s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x]; }
+	if (STRIDED) { __syncthreads(); build_stride_table(s_per_sample, s_stride); }
 	stage_jump31(s_jump);
 	const bool det_bounded = scene_det_bounded(scene);
 	BvhView bv{};
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 		uint32_t rng = start;
 		float4 m = mean_io[li];
 		if (OUT_OF_STEP && !BVH) {
-			FusedLdsCtx c{ f, tris, mats, use_prim ? s_prim : nullptr, s_jump, s_per_sample, n_tris, det_bounded, mean_first, n_samples };
+			FusedLdsCtx c{ f, tris, mats, use_prim ? s_prim : nullptr, s_jump, s_stride, n_tris, det_bounded, mean_first, n_samples };
 			fused_samples_out_of_step<STRIDED>(c, true, px, py, start, rng, m, n_rays, n_diffuse);
 			mean_io[li] = m;
 			if (!STRIDED) rng_io[li] = rng;
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 			if (STRIDED) {
 				// next sample starts at step^stride(start); when this sample drew exactly `stride`
 				// numbers (always, at stride 35 on the default scene) that is the state we are in
-				if (draws != f.stride) rng = mat_apply_lds(s_per_sample, start);
+				if (draws != f.stride) rng = byte_jump(s_stride, start);
 				start = rng;
 			}
 		}
@@ -593,13 +596,14 @@ __global__ __launch_bounds__(kBlock, PT_FUSED_BVH_WAVES) void k_fused_bvh(FrameD
 	extern __shared__ float4 s_dyn[];
 	uint32_t* s_stack = reinterpret_cast<uint32_t*>(s_dyn);        // bvh_stack_depth x 256 words
 	__shared__ uint32_t s_jump[1024];
-	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1];
+	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1], s_stride[STRIDED ? 1024 : 1];
 	__shared__ uint32_t s_next;
 	if (STRIDED && threadIdx.x < 32) { s_first[threadIdx.x] = first.cols[threadIdx.x]; s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x]; }
+	if (STRIDED) { __syncthreads(); build_stride_table(s_per_sample, s_stride); }
 	if (threadIdx.x == 0) s_next = 0;
 	stage_jump31(s_jump);
 	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
-	FusedBvhCtx c{ f, make_bvh_view(scene, n_tris, n_mats, f.origin), tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_per_sample,
+	FusedBvhCtx c{ f, make_bvh_view(scene, n_tris, n_mats, f.origin), tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_stride,
 	               mean_first, n_samples, rng_io, mean_io };
 	__syncthreads();
 	uint32_t n_rays = 0, n_diffuse = 0;

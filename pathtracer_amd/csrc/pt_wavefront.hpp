@@ -192,16 +192,6 @@ __device__ __forceinline__ void shade_block(const ShadeCtx& c, uint32_t last_bou
 	}
 }
 
-// table[j][v] = step^stride(v << 8j) = xor of the columns 8j+i of step^stride over the set bits i of v (all lanes of the
-// block take part; a block barrier must follow before the table is read)
-__device__ __forceinline__ void build_stride_table(const uint32_t* __restrict__ stride_cols, uint32_t* __restrict__ s_stride) {
-	for (uint32_t e = threadIdx.x; e < 1024u; e += kQueueBlock) {
-		uint32_t j = e >> 8, v = e & 255u, x = 0;
-		for (uint32_t i = 0; i < 8; i++) x ^= stride_cols[8u * j + i] & (0u - ((v >> i) & 1u));
-		s_stride[e] = x;
-	}
-}
-
 // A whole pass of an LDS-resident scene in ONE launch: camera rays, the bounce loop, and the fold into the mean.
 //
 // Ownership.  Block b owns the pixel chunks {k : k % G == b} (256 pixels each) with ALL samples of the pass, and, like

@@ -60,6 +60,8 @@ int main(int argc, char** argv) {
 	static const ByteJump jump31 = make_byte_jump(31);
 	for (uint32_t k = 0; k < 1024u; k++) s_jump[k] = (&jump31.t[0][0])[k];
 	for (uint32_t b = 0; b < 32; b++) { s_first[b] = steps(1u << b, (unsigned long long)frame_first * f.stride); s_per[b] = steps(1u << b, f.stride); }
+	uint32_t* s_stride = exact<uint32_t>(1024);                     // step^stride as the kernels build it
+	for (unsigned t = 0; t < 256; t++) { threadIdx.x = t; build_stride_table(s_per, s_stride); }
 	const float4* tris = reinterpret_cast<const float4*>(blob + sizeof(SceneHeader));
 	unsigned long long rays = 0, diffuse = 0;
 	if (brute_force) {
@@ -85,7 +87,7 @@ int main(int argc, char** argv) {
 					if (strided) start = mat_apply_lds(s_first, start);
 					uint32_t r = start, n_rays = 0, n_diffuse = 0;
 					float4 m = in_range ? mean[li] : float4{ 0, 0, 0, 0 };
-					FusedLdsCtx c{ f, tris, tris + (size_t)n_tris * 4, use_prim ? prim : nullptr, s_jump, s_per, n_tris, det_bounded, mean_first, n_samples };
+					FusedLdsCtx c{ f, tris, tris + (size_t)n_tris * 4, use_prim ? prim : nullptr, s_jump, s_stride, n_tris, det_bounded, mean_first, n_samples };
 					if (strided) fused_samples_out_of_step<true>(c, in_range, i % (uint32_t)f.width, i / (uint32_t)f.width, start, r, m, n_rays, n_diffuse);
 					else fused_samples_out_of_step<false>(c, in_range, i % (uint32_t)f.width, i / (uint32_t)f.width, start, r, m, n_rays, n_diffuse);
 					if (in_range) { mean[li] = m; if (!strided) rng[li] = r; }
@@ -118,7 +120,7 @@ int main(int argc, char** argv) {
 				th.emplace_back([&, w, l] {
 					threadIdx.x = w * 64 + (unsigned)l;
 					t_wave = &waves[w];
-					FusedBvhCtx c{ f, bv, tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_per, mean_first, n_samples, rng, mean };
+					FusedBvhCtx c{ f, bv, tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_stride, mean_first, n_samples, rng, mean };
 					const uint32_t first = blk * range, count = first < N ? std::min(range, N - first) : 0u;
 					uint32_t n_rays = 0, n_diffuse = 0;
 					if (strided) fused_bvh_block<true>(c, first, count, s_stack, &s_next, n_rays, n_diffuse);
