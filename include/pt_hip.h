@@ -65,6 +65,10 @@ enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
  * blob) and is traversed with it.  Recorded per scene at pack time: the launchers dispatch on this bit, never on the
  * process-wide threshold, so a blob packed under one threshold stays valid after pt_hip_set_bvh_threshold changes it. */
 #define PT_FRAME_SCENE_BVH 2u
+/* Scenes of MORE triangles than this are packed with a BVH unless pt_hip_set_bvh_threshold says otherwise.  Measured on
+ * MI355X at 1080p (tools/_sweep_bvh.py, profiles/r02_bvh_crossover.txt): the 48-triangle all-materials scene runs 2x faster
+ * looped over from LDS, at 108 triangles the BVH leads by 5 .. 22 % (level in one case of six), at 192 2x, at 432 4x .. 7x. */
+#define PT_BVH_DEFAULT_MIN_TRIANGLES 96u
 /* PT_FRAME_OUT_OF_STEP (pt_hip_render_fused, scenes without a BVH): the 64 pixels of a wave take their samples out of step --
  * a lane whose path has ended starts its pixel's next sample while its neighbours still bounce -- instead of bounce by bounce
  * together.  Same results bit for bit; faster where paths differ in length (deep scenes), slower where they do not (the
@@ -129,7 +133,7 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* waits for 
 
 /* ---- scene: Vertex/Triangle/Material arrays (Structures.cuh:43-69, upload PathTracer.cu:48-77)
  * packed once on the host into the device blob the kernels stage in LDS: per triangle
- * {v0, e0=v1-v0, e1=v2-v0, n=cross(e0,e1), materialIdx}, per material {type, color}; above 512
+ * {v0, e0=v1-v0, e1=v2-v0, n=cross(e0,e1), materialIdx}, per material {type, color}; above PT_BVH_DEFAULT_MIN_TRIANGLES
  * triangles also a BVH (32-byte nodes + 64-byte leaf records).
  * Validates vertex and material indices.  The blob is position independent: copy it to the
  * device with pt_hip_memcpy_h2d.  Entry points that take `scene_blob` also take the triangle and

@@ -31,6 +31,7 @@ PT_FRAME_FAST_DIV = 1
 PT_FRAME_SCENE_BVH = 2
 PT_FRAME_OUT_OF_STEP = 4
 PT_MAX_DEPTH = 32
+PT_BVH_DEFAULT_MIN_TRIANGLES = 96
 PT_STATS_PUBLIC_WORDS = 64
 PT_STATS_WORDS = PT_STATS_PUBLIC_WORDS + 32 * 16
 PT_NOALLOC_SCRATCH_BYTES = 64 << 20

@@ -32,7 +32,7 @@
 namespace ptbvh {
 
 #ifndef PT_BVH_LEAF
-#define PT_BVH_LEAF 4                              // triangles per leaf, at most 8 (the leaf code keeps count - 1 in 3 bits)
+#define PT_BVH_LEAF 2                              // triangles per leaf, at most 8 (the leaf code keeps count - 1 in 3 bits); measured: pt_device.hpp
 #endif
 constexpr uint32_t kLeafSize = PT_BVH_LEAF;        // == ptd::kBvhLeafSize (pt_device.hpp: the traversal stack is sized from it)
 static_assert(kLeafSize >= 1 && kLeafSize <= 8, "leaf code holds count - 1 in 3 bits");
@@ -67,23 +67,30 @@ struct LeafTri { float f[16]; };
 
 // ---- normal classes: a tight inflation for rays that graze nothing ----
 // The worst case kappa_i * S above (det barely above EPSILON) belongs to a GRAZING ray: det_true = |d| |e0||e1| sin(phi)
-// |cos(theta)| (phi between the edges, theta between ray and normal).  If |cos(theta)| >= kRho and sin(phi) >= kSinFloor
+// |cos(theta)| (phi between the edges, theta between ray and normal).  If |cos(theta)| >= rho and sin(phi) >= kSinFloor
 // the same term-by-term bound reads
-//     delta <= 7 * eps * S / (kRho * sin(phi))  <=  kKappaLo * S,     kKappaLo = 11 * eps / (kRho * kSinFloor)
-// whatever the triangle's size (no EPSILON in it: det_true is bounded directly) -- 1.3e-4 * S against 7e-3 * S for the
-// quads of the 10 092-triangle scene, whose boxes the worst case makes half as wide again.
-// So the builder sorts the triangles' planes (normals, sign-agnostic) into at most kMaxClasses classes, each a cone
-// {axis, tau = sin(half-angle + asin(kRho)) with margins}: a ray with |dhat . axis| >= tau is at least asin(kRho) away
-// from grazing EVERY triangle of the class.  A ray that passes this test for all classes of a scene whose triangles all
-// belong to one ("calm" ray: 94 % of the rays in an axis-aligned room) inflates every box by kKappaLo * S only; any other
-// ray, and every ray of a scene with slivers or more plane directions than classes, keeps the worst case as before.
-constexpr float kRho = 0.02f;                      // |cos(ray, normal)| from which a hit counts as "not grazing"
+//     delta <= 7 * eps * S / (rho * sin(phi))  <=  kKappaRho / rho * S,     kKappaRho = 11 * eps / kSinFloor
+// whatever the triangle's size (no EPSILON in it: det_true is bounded directly; the determinant's own relative error,
+// 4 eps / (rho sin(phi)) <= 1e-3 at rho = kRhoMin, is inside the 11-for-7 head-room) -- at rho = 0.02 that is 1.3e-4 * S against
+// 7e-3 * S for the quads of the 10 092-triangle scene, whose boxes the worst case makes half as wide again.
+// So the builder sorts the triangles' planes (normals, sign-agnostic) into at most kMaxClasses classes, each a cone of
+// half-angle h around an axis, stored as {axis * cos(h), sin(h)} (with margins): for a ray at angle beta to the plane
+// perpendicular to the axis, sin(beta) = |dhat . axis|, and its angle to any plane of the class is at least beta - h, so
+//     |cos(theta)| >= sin(beta - h) >= |dhat . axis| cos(h) - sin(h)  =: rho_k      (one dot product and a subtraction)
+// for EVERY triangle of the class.  In a scene whose triangles all belong to a class, rho = min_k rho_k bounds how close
+// to grazing a ray comes to anything, and the ray inflates every box by
+//     min(worst case, kKappaRho / rho * S),     kKappaRho = 11 * eps / kSinFloor
+// -- graded, not a two-way choice: in an axis-aligned room 94 % of the rays have rho >= 0.02 (1.3e-4 * S or less), 4.5 % lie
+// between 0.005 and 0.02 (at most 5e-4 * S), and only the last fraction of a per cent keeps the worst case -- which on scenes
+// of a few hundred LARGE triangles is larger than the boxes themselves (300 triangles: 0.15 * S), so every ray that fell
+// back to it tested the whole scene.  Rays of a scene with slivers or more plane directions than classes keep the worst case.
+constexpr float kRhoMin = 1e-3f;                   // == ptd::kBvhRhoMin: below this |cos(ray, normal)| bound a ray counts as grazing (worst case)
 constexpr float kSinFloor = 0.25f;                 // triangles whose edges e0, e1 are closer to parallel than this are never classified
-constexpr float kKappaLo = 11.0f * kEps32 / (kRho * kSinFloor);      // == ptd::kBvhKappaLo
+constexpr float kKappaRho = 11.0f * kEps32 / kSinFloor;      // == ptd::kBvhKappaRho
 constexpr uint32_t kMaxClasses = 8;                // == ptd::kBvhMaxClasses
 constexpr double kClassAngle = 0.14;               // radians (8 degrees): how far a normal may be from its class's axis
 
-struct NormalClass { float axis[3], tau; };        // 16 bytes, what the traversal reads
+struct NormalClass { float axis[3], sin_h; };      // 16 bytes, what the traversal reads: axis * cos(h) (rounded down), sin(h) (rounded up)
 struct ClassBlock {                                // 192 bytes at the end of the BVH part of the blob
 	uint32_t n_classes, all_classified, _pad[2];
 	NormalClass cls[kMaxClasses];
@@ -131,12 +138,13 @@ inline ClassBlock classify_normals(const std::vector<double>& n, const std::vect
 	out.n_classes = k_used;
 	out.all_classified = (all && count > 0) ? 1u : 0u;
 	for (uint32_t k = 0; k < k_used; k++) {
-		float axf[3] = { (float)axes[k][0], (float)axes[k][1], (float)axes[k][2] };      // the traversal uses the rounded axis: measure against it
-		double alen = std::sqrt((double)axf[0] * axf[0] + (double)axf[1] * axf[1] + (double)axf[2] * axf[2]);
-		// members were accepted against the double axis; the float axis differs by < 1e-7 rad, the 1e-3 rad below covers it
-		double angle = std::acos(std::min(1.0, cos_h[k])) + std::asin((double)kRho) + 1e-3;
-		for (int c = 0; c < 3; c++) out.cls[k].axis[c] = axf[c];
-		out.cls[k].tau = (float)(std::sin(angle) * alen * 1.0001 + 1e-5);     // |dhat . axf| = |axf| |cos|: alen folds the axis' own length in
+		// members were accepted against the double axis; the stored float axis differs by < 1e-7 rad, the 1e-3 rad below covers it
+		double h = std::acos(std::min(1.0, cos_h[k])) + 1e-3;
+		double alen = std::sqrt(axes[k][0] * axes[k][0] + axes[k][1] * axes[k][1] + axes[k][2] * axes[k][2]);
+		// the traversal's dhat is good to ~1e-6 (v_rcp) and its dot product to a few ulp: 1e-4 relative on the axis and 1e-5
+		// absolute on sin(h) keep the computed rho_k below the true |dhat . axis| cos(h) - sin(h)
+		for (int c = 0; c < 3; c++) out.cls[k].axis[c] = (float)(axes[k][c] / alen * std::cos(h) * (1.0 - 1e-4));
+		out.cls[k].sin_h = (float)(std::sin(h) * 1.0001 + 1e-5);
 	}
 	return out;
 }

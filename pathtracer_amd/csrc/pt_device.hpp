@@ -178,13 +178,17 @@ constexpr uint32_t kSceneDetBounded = 1u;              // max |e0|*|e1| < 2^100:
 static_assert(sizeof(SceneHeader) == 64, "SceneHeader is 64 bytes");
 
 // Scenes above this many triangles carry a BVH and are traversed with it (pt_bvh.hpp).
-constexpr uint32_t kBvhMinTris = 512;    // measured crossover on MI355X: brute force wins at 432 triangles, the BVH 2-3x at 972
+constexpr uint32_t kBvhMinTris = PT_BVH_DEFAULT_MIN_TRIANGLES;    // the measured crossover: pt_hip.h
 // Per-lane stack of deferred children, in LDS, [level][256 lanes]: one deferred sibling per inner level, so the tree's
 // depth is the most it can ever hold.  It is sized from the triangle count alone -- the depth of a balanced tree with
 // kBvhLeafSize triangles per leaf plus kBvhDepthSlack levels -- and the builder (pt_bvh.hpp) keeps its surface-area
 // splits inside that budget; 24 KiB for a fixed depth of 24 would cap a CU at 6 blocks.
+// Triangles per leaf.  Round 1 (boxes inflated for the worst case): 2, 4 and 8 within 3 % of each other.  With the graded
+// inflation (bvh_ray_setup) a box test prunes what it should and a triangle test (three 16-byte loads) is the dearer step:
+// 10 092 triangles, wavefront / fused engine, 1 / 2 / 4 / 8 per leaf: 11.5 / 12.7 / 12.0 / - and 9.6 / 11.1 / 10.2 / - Grays/s;
+// bounced rays in the extend stage alone 10.6 / 12.6 / 12.0 / 10.1 (99 372 triangles: - / 7.8 / 7.5 / 6.0).
 #ifndef PT_BVH_LEAF
-#define PT_BVH_LEAF 4
+#define PT_BVH_LEAF 2
 #endif
 constexpr uint32_t kBvhLeafSize = PT_BVH_LEAF;     // == ptbvh::kLeafSize
 constexpr uint32_t kBvhDepthSlack = 3;     // levels the builder may spend on unbalanced (surface-area) splits, pt_bvh.hpp
@@ -197,11 +201,12 @@ __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block
 constexpr uint32_t kBvhClassBytes = 192;    // pt_bvh.hpp ClassBlock
 constexpr uint32_t kBvhMaxClasses = 8;      // == ptbvh::kMaxClasses
-constexpr float kBvhKappaLo = 11.0f * 5.9604645e-8f / (0.02f * 0.25f);     // == ptbvh::kKappaLo: inflation per unit of S for a ray that grazes nothing
+constexpr float kBvhKappaRho = 11.0f * 5.9604645e-8f / 0.25f;     // == ptbvh::kKappaRho: inflation per unit of S, times the ray's rho (pt_bvh.hpp, normal classes)
+constexpr float kBvhRhoMin = 1e-3f;                              // == ptbvh::kRhoMin
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
-constexpr uint32_t kSceneMagic = 0x50544854u;  // "PTHT" (T: half nodes {box, child}; a blob of the older node layout is refused)
+constexpr uint32_t kSceneMagic = 0x50544855u;  // "PTHU" (T: half nodes {box, child}; U: normal classes as {axis cos h, sin h}; older blobs are refused)
 
 // The 16-bit grid the BVH's boxes are stored on (pt_bvh.hpp QNode): a cube around the scene's bounding sphere,
 // x = lo + q * cell, q = 0..65535.  Host (scene_pack) and device evaluate this same function.
@@ -309,8 +314,8 @@ struct BvhView {
 	float max_edge;          // longest triangle edge
 	bool det_bounded;        // SceneHeader::flags bit 0
 	int stack_depth;         // bvh_stack_depth(n_tris)
-	const float4* classes;   // pt_bvh.hpp NormalClass {axis, tau} x n_classes (wave-uniform reads)
-	uint32_t n_classes;      // 0: no ray is ever "calm" (slivers, or more plane directions than classes)
+	const float4* classes;   // pt_bvh.hpp NormalClass {axis * cos(h), sin(h)} x n_classes (wave-uniform reads)
+	uint32_t n_classes;      // 0: every ray keeps the worst-case inflation (slivers, or more plane directions than classes)
 	uint32_t n_nodes, n_tris; // sizes of `nodes` and `leaves`
 };
 
@@ -479,19 +484,24 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	float delta_max = bv.kappa_root * bv.s_bound + bv.slack;
 	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
 	float delta_root = bv.kappa_root * s_ray + bv.slack;     // how far outside its triangle an accepted hit can be
-	r.dt = 1.01f * delta_root / dlen;                        // ... in ray-parameter units (the worst case for every ray: it only widens [tlo, thi])
-	// A "calm" ray -- at least asin(kRho) away from grazing every triangle of the scene (pt_bvh.hpp, normal classes) -- needs
-	// only the size-independent inflation for the boxes.  dhat to ~1e-6 (v_rcp): tau carries 1e-4 relative + 1e-5 for it.
-	bool calm = bv.n_classes != 0u;
+	// How close to grazing does this ray come to ANY triangle of the scene?  rho = min over the normal classes of
+	// |dhat . axis| cos(h) - sin(h) <= |cos(ray, normal)| (pt_bvh.hpp; the stored axis and sin(h) carry the margins for the
+	// ~1e-6 of dhat's v_rcp).  The boxes are inflated by kBvhKappaRho / rho * S -- size-independent, and graded: the closer to
+	// grazing, the wider -- never by more than the worst case, which is also what a ray below kBvhRhoMin gets.
+	float rho = bv.n_classes != 0u ? 1.0f : 0.0f;
 	{
 		float il = __builtin_amdgcn_rcpf(dlen);
 		Vec3 dh{ dd.x * il, dd.y * il, dd.z * il };
 		for (uint32_t k = 0; k < bv.n_classes; k++) {
 			float4 c = bv.classes[k];
-			calm = calm && fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) >= c.w;
+			rho = fminf(rho, fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) - c.w);
 		}
 	}
-	float delta_box = calm ? fminf(kBvhKappaLo, bv.kappa_root) * s_ray + bv.slack : delta_root;
+	float delta_box = delta_root;
+	if (rho >= kBvhRhoMin) delta_box = fminf(delta_root, 1.0001f * kBvhKappaRho * __builtin_amdgcn_rcpf(rho) * s_ray + bv.slack);
+	// the same bound holds for the hit distance (t = f * (e1 . q) carries the same 1 / det): |t_true - t| |d| <= delta_box,
+	// so the ray interval is widened to [-dt, best_t + dt] with it
+	r.dt = 1.01f * delta_box / dlen;
 	// The origin in grid units.  Its own rounding (a subtraction, a product with the rounded 1/cell: under 4 ulp of a
 	// value that can reach 65535 + the camera's distance) and that of the slab's (q - o) go into the inflation, four
 	// times over: 1e-6 of the magnitudes involved -- hundredths of a cell, against boxes tens of cells wide.

@@ -911,7 +911,7 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			std::vector<ptbvh::QNode> qnodes = ptbvh::quantize(bvh.nodes, glo, cell);
 			std::memcpy(base + hdr.bvh_offset, qnodes.data(), qnodes.size() * sizeof(ptbvh::QNode));
 			std::memcpy(base + hdr.leaf_offset, bvh.tris.data(), bvh.tris.size() * sizeof(ptbvh::LeafTri));
-			static_assert(sizeof(ptbvh::ClassBlock) == kBvhClassBytes && ptbvh::kMaxClasses == kBvhMaxClasses && ptbvh::kKappaLo == kBvhKappaLo,
+			static_assert(sizeof(ptbvh::ClassBlock) == kBvhClassBytes && ptbvh::kMaxClasses == kBvhMaxClasses && ptbvh::kKappaRho == kBvhKappaRho && ptbvh::kRhoMin == kBvhRhoMin,
 			              "pt_bvh.hpp and pt_device.hpp disagree on the normal classes");
 			std::memcpy(base + hdr.leaf_offset + (size_t)n_triangles * 64u, &bvh.classes, sizeof(bvh.classes));
 			for (int k = 0; k < 3; k++) hdr.center[k] = bvh.center[k];

@@ -51,7 +51,7 @@ def test_scene_pack_matches_reference_arithmetic(pt):
     lib = pt.load_library()
     v, t, m = pt.default_scene()
     n = lib.pt_hip_scene_blob_bytes(4, 2)
-    assert n == 64 + 4 * 64 + 2 * 32            # 64-byte header, 64 B per triangle, 32 B per material (no BVH up to 512 triangles)
+    assert n == 64 + 4 * 64 + 2 * 32            # 64-byte header, 64 B per triangle, 32 B per material (no BVH up to PT_BVH_DEFAULT_MIN_TRIANGLES triangles)
     blob = (C.c_uint8 * n)()
     rc = lib.pt_hip_scene_pack(C.cast(v, C.c_void_p), 8, C.cast(t, C.c_void_p), 4, C.cast(m, C.c_void_p), 2, C.cast(blob, C.c_void_p), n)
     assert rc == 0, lib.pt_hip_last_error()
@@ -121,7 +121,7 @@ def test_workspace_size_accounts_for_every_buffer(pt):
 
 
 def test_bvh_blob_is_a_valid_hierarchy(pt):
-    """Scenes above 512 triangles carry a BVH (pathtracer_amd/csrc/pt_bvh.hpp): every triangle is in
+    """Scenes above PT_BVH_DEFAULT_MIN_TRIANGLES (96) triangles carry a BVH (pathtracer_amd/csrc/pt_bvh.hpp): every triangle is in
     exactly one leaf, every child box (on its 16-bit grid) contains its triangles and lies in its parent's."""
     import scenes
     lib = pt.load_library()
@@ -139,12 +139,12 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     assert hdr_f[12] > 0 and hdr_f[13] > 0                       # radius, kappa_root
     # QNode, 32 bytes = two half nodes of {3 words {lo, hi} uint16 grid coordinates, child word}; the grid is bvh_grid(center, radius)
     balanced, k = 0, n_tris
-    while k > 4:
+    while k > 2:
         k, balanced = (k + 1) // 2, balanced + 1
     # the blob: header, triangles, materials | nodes | leaf records | normal classes
     assert n == bvh_off + (32 + 64) * n_tris + 192
-    # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis, tau}: every triangle's plane lies in one of the cones, and
-    # |cos(axis, normal)| >= cos(half-angle) with tau = sin(half-angle + asin(0.02)) (+ margins) for all of its members
+    # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis * cos(h), sin(h)}: every triangle's plane lies in one of the
+    # cones (half-angle h around the axis), so |dhat . axis| cos(h) - sin(h) bounds |cos(ray, normal)| from below
     cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 192]
     n_classes, all_classified = int(cb[:8].view(np.uint32)[0]), int(cb[:8].view(np.uint32)[1])
     cls = cb[16:16 + 16 * 8].view(np.float32).reshape(8, 4).astype(np.float64)
@@ -156,11 +156,19 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     for nv in nrm:
         ok = False
         for k in range(n_classes):
-            ax, tau = cls[k, :3], cls[k, 3]
-            cos_h = abs(ax @ nv) / np.linalg.norm(ax)
-            if np.arcsin(min(1.0, tau / np.linalg.norm(ax))) >= np.arccos(min(1.0, cos_h)) + np.arcsin(0.02):
+            ax, sin_h = cls[k, :3], cls[k, 3]
+            cos_to_axis = abs(ax @ nv) / np.linalg.norm(ax)
+            # the normal lies inside the cone the class claims: both the stored sin(h) and the stored cos(h) = |axis| say so
+            if np.arcsin(min(1.0, sin_h)) >= np.arccos(min(1.0, cos_to_axis)) and np.linalg.norm(ax) <= cos_to_axis:
                 ok = True
         assert ok
+    # ... and the bound itself, on random directions: rho_k <= |cos(ray, normal)| for every triangle of class k
+    dirs = np.random.default_rng(3).normal(size=(400, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    for k in range(n_classes):
+        members = nrm[np.abs(nrm @ (cls[k, :3] / np.linalg.norm(cls[k, :3]))) > np.cos(0.15)]
+        rho_k = np.abs(dirs @ cls[k, :3]) - cls[k, 3]
+        assert (rho_k[:, None] <= np.abs(dirs @ members.T) + 1e-12).all()
     nodes_q = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.uint16).reshape(n_nodes, 16)
     nodes_i = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.int32).reshape(n_nodes, 8)
     half = np.float32(1.0001) * hdr_f[12] + np.float32(1e-6)
@@ -204,7 +212,7 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     sys.setrecursionlimit(10000)
     visit(0, np.full(3, -np.inf), np.full(3, np.inf))
     assert (seen == 1).all()
-    # the traversal's stack is sized from the triangle count alone (bvh_stack_depth: balanced depth of 4-triangle leaves + 3
+    # the traversal's stack is sized from the triangle count alone (bvh_stack_depth: balanced depth of 2-triangle leaves + 3
     # levels of slack for surface-area splits); the builder must stay inside it
     assert 0 < deepest[0] <= balanced + 3
     # the knob: brute force only
@@ -212,4 +220,4 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     try:
         assert lib.pt_hip_scene_blob_bytes(len(T), len(M)) == 64 + 64 * len(T) + 32 * len(M) + (-(64 * len(T) + 32 * len(M)) % 64)
     finally:
-        lib.pt_hip_set_bvh_threshold(512)
+        lib.pt_hip_set_bvh_threshold(pt.PT_BVH_DEFAULT_MIN_TRIANGLES)

@@ -74,6 +74,29 @@ def sheets_scene(per_side, offset=(0.0, 0.0, 0.0)):
     return V, T, MATS
 
 
+def tilted_room(n_tris, seed, tilt, rotate=True):
+    """the synthetic box of LARGE quads (scenes.synthetic_scene: a few hundred triangles, worst-case inflation larger than the
+    boxes), every quad turned about its own centre by up to `tilt` radians and the whole room by a random rotation: the normal
+    classes get cones of non-zero half-angle around axes that are no coordinate axes, which is where the graded inflation
+    (pt_bvh.hpp: |dhat . axis| cos(h) - sin(h)) has to hold"""
+    import scenes
+    rng = np.random.default_rng(seed)
+    V, T, _ = scenes.synthetic_scene(n_tris)
+    P = np.array([v[:3] for v in V], dtype=np.float64)
+
+    def rotation(angle_max):
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        ang = rng.uniform(-angle_max, angle_max)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    for q in range(len(V) // 4):                                   # _quad appends four vertices per quad
+        c = P[4 * q:4 * q + 4].mean(0)
+        P[4 * q:4 * q + 4] = (P[4 * q:4 * q + 4] - c) @ rotation(tilt).T + c
+    if rotate:
+        P = (P - np.array([0.0, 0.0, 0.5])) @ rotation(np.pi).T
+    return [_f32(p) for p in P], [(a, b, c, m % 3) for (a, b, c, m) in T], MATS
+
+
 def grazing_rays(V, T, n_rays, seed):
     """rays aimed at points on and just off the edges of chosen triangles, almost in their planes, from inside the scene's ball"""
     rng = np.random.default_rng(seed)
@@ -117,7 +140,9 @@ def grazing_rays(V, T, n_rays, seed):
 
 CASES = [("slivers", lambda: sliver_scene(900, 1)), ("slivers far from the origin", lambda: sliver_scene(700, 2, offset=(300.0, -120.0, 75.0))),
          ("four decades of sizes", lambda: scales_scene(1500, 3)), ("four decades, far from the origin", lambda: scales_scene(900, 4, offset=(-64.0, 200.0, 31.0))),
-         ("coplanar sheets", lambda: sheets_scene(12)), ("coplanar sheets far from the origin", lambda: sheets_scene(10, offset=(1000.0, 1000.0, -1000.0)))]
+         ("coplanar sheets", lambda: sheets_scene(12)), ("coplanar sheets far from the origin", lambda: sheets_scene(10, offset=(1000.0, 1000.0, -1000.0))),
+         ("room of large quads", lambda: tilted_room(300, 5, 0.0, rotate=False)), ("rotated room of large tilted quads", lambda: tilted_room(432, 6, 0.05)),
+         ("rotated room, quads tilted to the edge of their class", lambda: tilted_room(300, 7, 0.12))]
 
 
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
@@ -125,7 +150,7 @@ def test_grazing_rays_get_the_brute_force_answer(pt, tmp_path, name, make):
     if not os.path.exists(CHECK):
         pytest.skip("tests/host/bvh_host_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
     V, T, M = make()
-    assert len(T) > 512                                              # above the BVH threshold
+    assert len(T) > pt.PT_BVH_DEFAULT_MIN_TRIANGLES                                              # above the BVH threshold
     n_rays = 6000
     rays, centre = grazing_rays(V, T, n_rays, seed=len(T))
     blob, rfile = tmp_path / "scene.blob", tmp_path / "rays.f32"

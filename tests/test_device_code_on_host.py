@@ -78,7 +78,7 @@ def test_all_materials_depth_16_and_moved_camera(pt, oracle, tmp_path):
 
 
 @needs_binary
-@pytest.mark.parametrize("n_tris", [300, 700, 2500])
+@pytest.mark.parametrize("n_tris", [192, 300, 700, 2500])
 def test_synthetic_scenes_brute_force_and_bvh(pt, oracle, tmp_path, n_tris):
     """300 triangles: the loop over all triangles with the camera-ray records; 700 and 2500: the BVH walk."""
     V, T, M = scenes.synthetic_scene(n_tris)

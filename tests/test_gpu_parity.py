@@ -254,7 +254,7 @@ def brute_force_only(pt):
     lib = pt.load_library()
     lib.pt_hip_set_bvh_threshold(0xFFFFFFFF)
     yield
-    lib.pt_hip_set_bvh_threshold(512)
+    lib.pt_hip_set_bvh_threshold(pt.PT_BVH_DEFAULT_MIN_TRIANGLES)
 
 
 def _synthetic_case(pt, oracle, name, engine, n_tris):
@@ -271,11 +271,36 @@ def _synthetic_case(pt, oracle, name, engine, n_tris):
 
 
 @pytest.mark.parametrize("name,engine", ENGINES)
-@pytest.mark.parametrize("n_tris", [12, 300, 512, 520, 1100, 2500, 20000])
+@pytest.mark.parametrize("n_tris", [12, 108, 192, 300, 588, 1100, 2500, 20000])
 def test_synthetic_scenes(pt, oracle, name, engine, n_tris):
-    """BASELINE.json configs[3] at test size.  Above 512 triangles the extend stage walks a BVH whose
-    answer must be the brute-force one bit for bit (the oracle is brute force)."""
+    """BASELINE.json configs[3] at test size.  Above PT_BVH_DEFAULT_MIN_TRIANGLES (96) triangles the extend stage walks a BVH
+    whose answer must be the brute-force one bit for bit (the oracle is brute force)."""
     _synthetic_case(pt, oracle, name, engine, n_tris)
+
+
+@pytest.mark.parametrize("name,engine", ENGINES)
+@pytest.mark.parametrize("keep", [96, 97])
+def test_scenes_on_either_side_of_the_bvh_threshold(pt, oracle, name, engine, keep):
+    """the first 96 / 97 triangles of the 300-triangle box (open: some rays leave): the last scene that is looped over,
+    the first that carries a BVH"""
+    import ctypes as C
+    V, T, M = scenes.synthetic_scene(300)
+    T = T[:keep]
+    lib = pt.load_library()
+    v, t, m = pt.make_scene(V, T, M)
+    n = lib.pt_hip_scene_blob_bytes(len(T), len(M))
+    blob = (C.c_uint8 * n)()
+    assert lib.pt_hip_scene_pack(C.cast(v, C.c_void_p), len(V), C.cast(t, C.c_void_p), len(T), C.cast(m, C.c_void_p), len(M), C.cast(blob, C.c_void_p), n) == 0
+    assert lib.pt_hip_scene_has_bvh(C.cast(blob, C.c_void_p), n) == (1 if keep > pt.PT_BVH_DEFAULT_MIN_TRIANGLES else 0)
+    w, h, spp = 64, 40, 3
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine)
+        tr.render(spp)
+        img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
+    assert_bit_equal(img, ref, f"{name} {keep} triangles")
+    assert np.array_equal(rng, ref_rng) and st.rays == st_ref.rays
 
 
 @pytest.mark.parametrize("name,engine", ENGINES)
@@ -297,7 +322,7 @@ def test_bvh_equals_brute_force_on_every_pixel(pt, oracle, name, engine, n_tris,
     w, h = 960, 540
     lib = pt.load_library()
     imgs = []
-    for threshold in (512, 0xFFFFFFFF):
+    for threshold in (pt.PT_BVH_DEFAULT_MIN_TRIANGLES, 0xFFFFFFFF):
         lib.pt_hip_set_bvh_threshold(threshold)
         try:
             with pt.PathTracer(w, h) as tr:
@@ -306,7 +331,7 @@ def test_bvh_equals_brute_force_on_every_pixel(pt, oracle, name, engine, n_tris,
                 tr.render(spp)
                 imgs.append((tr.readback(), tr.readback_rng(), tr.stats().rays))
         finally:
-            lib.pt_hip_set_bvh_threshold(512)
+            lib.pt_hip_set_bvh_threshold(pt.PT_BVH_DEFAULT_MIN_TRIANGLES)
     assert_bit_equal(imgs[0][0], imgs[1][0], f"{name}: BVH vs brute force")
     assert np.array_equal(imgs[0][1], imgs[1][1]) and imgs[0][2] == imgs[1][2]
     ids = np.unique(np.random.default_rng(11).integers(0, w * h, 300)).astype(np.uint32)
@@ -529,13 +554,13 @@ def test_statistics_at_the_depth_limit(pt, oracle, name, engine, depth):
 
 
 def test_blob_keeps_its_bvh_decision_when_the_threshold_moves(pt, oracle):
-    """A scene packed while the BVH threshold was lifted (brute force) and rendered after it is back to 512, and the other
+    """A scene packed while the BVH threshold was lifted (brute force) and rendered after it is back to its default, and the other
     way round: the launchers dispatch on what the blob carries, not on the process-wide knob."""
     V, T, M = scenes.synthetic_scene(1100)
     w, h, spp = 64, 40, 2
     ref, _, st_ref, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
     lib = pt.load_library()
-    for packed_under, rendered_under in ((0xFFFFFFFF, 512), (512, 0xFFFFFFFF)):
+    for packed_under, rendered_under in ((0xFFFFFFFF, pt.PT_BVH_DEFAULT_MIN_TRIANGLES), (pt.PT_BVH_DEFAULT_MIN_TRIANGLES, 0xFFFFFFFF)):
         for name, engine in ENGINES:
             try:
                 with pt.PathTracer(w, h) as tr:
@@ -546,7 +571,7 @@ def test_blob_keeps_its_bvh_decision_when_the_threshold_moves(pt, oracle):
                     tr.render(spp)
                     img, st = tr.readback(), tr.stats()
             finally:
-                lib.pt_hip_set_bvh_threshold(512)
+                lib.pt_hip_set_bvh_threshold(pt.PT_BVH_DEFAULT_MIN_TRIANGLES)
             assert_bit_equal(img, ref, f"{name} packed under {packed_under:#x}, rendered under {rendered_under:#x}")
             assert st.rays == st_ref.rays
 

@@ -163,7 +163,7 @@ def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
     V, T, M = {"default": scenes.default_scene, "materials": scenes.all_materials_scene, "synthetic2500": lambda: scenes.synthetic_scene(2500)}[scene_name]()
     w, h = 200, 120
     ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=7), scene=oracle.make_scene(V, T, M))
-    has_bvh = len(T) > 512
+    has_bvh = len(T) > pt.PT_BVH_DEFAULT_MIN_TRIANGLES
     with pt.PathTracer(w, h) as tr:
         assert tr.get_options().engine == pt.PT_ENGINE_AUTO
         tr.set_scene(*pt.make_scene(V, T, M))

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pathtracer_amd as pt, scenes
 cases = [("default", None, 10, 0), ("all materials depth 16", scenes.all_materials_scene(), 16, 0), ("mirror, extended, depth 16", scenes.mirror_scene(), 16, 1),
-         ("synthetic 300 (brute force)", scenes.synthetic_scene(300), 10, 0)]
+         ("synthetic 192 (brute force)", scenes.synthetic_scene(192), 10, 0)]
 for name, sc, depth, shading in cases:
     imgs = []
     for oos in (0, 1):
