@@ -1,6 +1,8 @@
-for v in base leaf2 leaf1; do
+for v in $VARIANTS; do
+  for w in c4_10k; do
   for e in wavefront fused; do
-    echo -n "$v $e: "
-    PT_HIP_LIBRARY=$PWD/_ab/lib$v.so timeout -k 10 200 python3 bench.py --bare --workload c4_10k --engine $e --steps 5 --warmup 2 2>/dev/null | grep "^{" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" || exit 1
+    echo -n "$v $w $e: "
+    PT_HIP_LIBRARY=$PWD/_ab/lib$v.so timeout -k 10 200 python3 bench.py --bare --workload $w --engine $e --steps 5 --warmup 2 2>/dev/null | grep "^{" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" || exit 1
+  done
   done
 done

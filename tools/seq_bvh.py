@@ -1,3 +1,4 @@
+"""BVH scenes under the reference's own sequential streams: fused / wavefront / PT_ENGINE_AUTO, 8 samples per call, Mrays/s (device time)."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import pathtracer_amd as pt, scenes
@@ -8,6 +9,6 @@ for n in (1000, 10000, 100000):
             with pt.PathTracer(w, h) as tr:
                 tr.set_scene(*sc)
                 tr.set_options(engine=engine)
-                tr.render(2); tr.render(2)
+                for _ in range(5): tr.render(8)          # (PT_ENGINE_AUTO measures its candidates on the first renders of a sample count)
                 s0 = tr.stats(); tr.render(8); s1 = tr.stats()
                 print(f"{n} triangles {w}x{h} sequential {name:9s}: {(s1.rays - s0.rays) / (s1.total_render_ms - s0.total_render_ms) / 1e3:8.1f} Mrays/s  in use {s1.engine_in_use}", flush=True)
