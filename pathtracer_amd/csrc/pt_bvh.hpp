@@ -70,8 +70,9 @@ struct LeafTri { float f[16]; };
 // |cos(theta)| (phi between the edges, theta between ray and normal).  If |cos(theta)| >= rho and sin(phi) >= kSinFloor
 // the same term-by-term bound reads
 //     delta <= 7 * eps * S / (rho * sin(phi))  <=  kKappaRho / rho * S,     kKappaRho = 11 * eps / kSinFloor
-// whatever the triangle's size (no EPSILON in it: det_true is bounded directly; the determinant's own relative error,
-// 4 eps / (rho sin(phi)) <= 1e-3 at rho = kRhoMin, is inside the 11-for-7 head-room) -- at rho = 0.02 that is 1.3e-4 * S against
+// whatever the triangle's size (no EPSILON in it: det_true is bounded directly; the computed determinant's own relative
+// error e = 4 eps / (rho sin(phi)) scales the bound by 1 / (1 - e): 1 % at rho = kRhoMin, inside the 11-for-7 head-room,
+// which would last down to rho = 3e-6) -- at rho = 0.02 that is 1.3e-4 * S against
 // 7e-3 * S for the quads of the 10 092-triangle scene, whose boxes the worst case makes half as wide again.
 // So the builder sorts the triangles' planes (normals, sign-agnostic) into at most kMaxClasses classes, each a cone of
 // half-angle h around an axis, stored as {axis * cos(h), sin(h)} (with margins): for a ray at angle beta to the plane
@@ -81,10 +82,11 @@ struct LeafTri { float f[16]; };
 // to grazing a ray comes to anything, and the ray inflates every box by
 //     min(worst case, kKappaRho / rho * S),     kKappaRho = 11 * eps / kSinFloor
 // -- graded, not a two-way choice: in an axis-aligned room 94 % of the rays have rho >= 0.02 (1.3e-4 * S or less), 4.5 % lie
-// between 0.005 and 0.02 (at most 5e-4 * S), and only the last fraction of a per cent keeps the worst case -- which on scenes
+// between 0.005 and 0.02 (at most 5e-4 * S), and only what lies below kRhoMin (3 rays in 10 000) keeps the worst case -- which on scenes
 // of a few hundred LARGE triangles is larger than the boxes themselves (300 triangles: 0.15 * S), so every ray that fell
-// back to it tested the whole scene.  Rays of a scene with slivers or more plane directions than classes keep the worst case.
-constexpr float kRhoMin = 1e-3f;                   // == ptd::kBvhRhoMin: below this |cos(ray, normal)| bound a ray counts as grazing (worst case)
+// back to it tested the whole scene, holding its wave for the time of twenty (measured with the cut at 1e-3, 3 rays in
+// 1000: the fused engine ran 192..588 triangles at 4.0..6.5 Grays/s between 9.1 at 108 and 9.6 at 972).  Rays of a scene with slivers or more plane directions than classes keep the worst case.
+constexpr float kRhoMin = 1e-4f;                   // == ptd::kBvhRhoMin: below this |cos(ray, normal)| bound a ray counts as grazing (worst case)
 constexpr float kSinFloor = 0.25f;                 // triangles whose edges e0, e1 are closer to parallel than this are never classified
 constexpr float kKappaRho = 11.0f * kEps32 / kSinFloor;      // == ptd::kBvhKappaRho
 constexpr uint32_t kMaxClasses = 8;                // == ptd::kBvhMaxClasses

@@ -202,7 +202,7 @@ constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserv
 constexpr uint32_t kBvhClassBytes = 192;    // pt_bvh.hpp ClassBlock
 constexpr uint32_t kBvhMaxClasses = 8;      // == ptbvh::kMaxClasses
 constexpr float kBvhKappaRho = 11.0f * 5.9604645e-8f / 0.25f;     // == ptbvh::kKappaRho: inflation per unit of S, times the ray's rho (pt_bvh.hpp, normal classes)
-constexpr float kBvhRhoMin = 1e-3f;                              // == ptbvh::kRhoMin
+constexpr float kBvhRhoMin = 1e-4f;                              // == ptbvh::kRhoMin
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
