@@ -184,3 +184,36 @@ def test_these_rays_do_reach_the_inflation(pt, tmp_path):
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([CHECK, str(bfile), str(rfile)] + [repr(c) for c in centre], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 1 and int(r.stdout.split()[5]) >= 1, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("tilt,rotate", [(0.0, False), (0.05, True), (0.12, True)])
+def test_rho_of_the_normal_classes_bounds_the_cosine_to_every_triangle(pt, tilt, rotate):
+    """What the graded inflation rests on (pt_bvh.hpp): rho(d) = min over the classes of |dhat . axis cos(h)| - sin(h), read
+    from the packed blob, is a LOWER bound on |cos(d, normal)| for every triangle of the scene -- random directions, directions
+    a hair off a triangle's plane, and directions on the rim of a class's cone."""
+    V, T, M = tilted_room(300, 11, tilt, rotate=rotate)
+    raw = np.frombuffer(pack(pt, V, T, M), dtype=np.uint8)
+    hdr = raw[:64].view(np.uint32)
+    n_tris, leaf_off = int(hdr[0]), int(hdr[8])
+    cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 192]
+    n_classes, all_classified = (int(x) for x in cb[:8].view(np.uint32))
+    assert all_classified == 1 and 3 <= n_classes <= 8
+    cls = cb[16:16 + 16 * n_classes].view(np.float32).reshape(n_classes, 4).astype(np.float64)
+    P = np.array([v[:3] for v in V], dtype=np.float64)
+    tri = np.array([t[:3] for t in T])
+    nrm = np.cross(P[tri[:, 1]] - P[tri[:, 0]], P[tri[:, 2]] - P[tri[:, 0]])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    rng = np.random.default_rng(17)
+    dirs = [rng.normal(size=(3000, 3))]
+    for k in rng.integers(0, len(T), 600):                         # almost in the plane of triangle k
+        inplane = np.cross(nrm[k], rng.normal(size=3))
+        dirs.append((inplane / np.linalg.norm(inplane) + nrm[k] * 10 ** rng.uniform(-6, -1) * rng.choice([-1, 1]))[None, :])
+    d = np.concatenate(dirs)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rho = (np.abs(d @ cls[:, :3].T) - cls[:, 3]).min(axis=1)
+    cos_min = np.abs(d @ nrm.T).min(axis=1)
+    assert (rho <= cos_min + 1e-12).all(), float((rho - cos_min).max())
+    # the bound is not vacuous: most random directions get a usable rho, and untilted rooms lose next to nothing
+    assert (rho[:3000] >= 0.02).mean() > (0.85 if tilt == 0.0 else 0.3)
+    if tilt == 0.0:
+        assert (cos_min[:3000] - rho[:3000]).max() < 2e-3
