@@ -29,6 +29,7 @@ box's cores).  Outside the timed region it also measures a sustained loop, the w
 BASELINE.json's configs[4] (all materials) and configs[3] (10 092 triangles, BVH), each with its own bound.
 """
 import argparse
+import functools
 import hashlib
 import json
 import os
@@ -59,6 +60,7 @@ WORKLOADS = {
     "default": ("default", 10, 35, "reference default scene (BASELINE.json configs[1])"),
     "c5": ("materials", 16, 2 + 33 * 16, "all materials, 48 triangles, depth 16 (BASELINE.json configs[4])"),
     "c4_10k": ("synthetic10000", 10, 2 + 33 * 10, "synthetic 10 092 triangles through the BVH (BASELINE.json configs[3])"),
+    "c4_100k": ("synthetic100000", 10, 2 + 33 * 10, "synthetic 99 372 triangles through the BVH (BASELINE.json configs[3], upper end)"),
 }
 
 
@@ -80,6 +82,7 @@ def load_counters():
         return {}
 
 
+@functools.lru_cache(maxsize=None)
 def scene_of(name):
     import scenes
     if name == "default":
@@ -302,7 +305,7 @@ def main():
             ta.Destroy()
             out["engine_auto_pick"] = {pt.PT_ENGINE_FUSED: "fused", pt.PT_ENGINE_WAVEFRONT: "wavefront"}.get(ma["engine_in_use"], "undecided")
             if args.workload == "default":
-                for wl, eng in (("c5", "wavefront"), ("c5", "fused"), ("c4_10k", "wavefront"), ("c4_10k", "fused")):
+                for wl, eng in (("c5", "wavefront"), ("c5", "fused"), ("c4_10k", "wavefront"), ("c4_10k", "fused"), ("c4_100k", "wavefront"), ("c4_100k", "fused")):
                     figures.append(side_figure(pt, counters, sha, wl, eng, w, h))
             out["other_figures"] = figures
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp) if args.cpu_spp > 0 else None

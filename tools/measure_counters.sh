@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 STEPS=8; WARM=1; SETTLE=4      # bench.py renders SETTLE untimed steps first (the plugin measures its candidates there)
-for wl in default c5 c4_10k; do
+for wl in default c5 c4_10k c4_100k; do
   for eng in fused wavefront; do
     i=0
     for c in "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE" "TA_TA_BUSY_sum GRBM_GUI_ACTIVE"; do
