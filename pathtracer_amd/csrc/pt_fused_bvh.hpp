@@ -35,11 +35,31 @@ struct FusedBvhCtx {
 	float4* mean_io;
 };
 
-// The block's pixels are [range_first, range_first + range_count) of the frame's pixel range (local indices); *s_next is
+// Which pixels of the frame's range (local indices) block b of G takes.  range == 0: INTERLEAVED -- the 64-pixel tiles b, b + G,
+// b + 2 G, ... (the range's last tile may be short): every block gets a sample of the whole image, so the blocks finish
+// together whatever the image shows where, and the grid can be exactly the blocks the machine holds at once (one drain per
+// launch).  Measured against contiguous ranges of the best length per case (tools/fused_range_sweep.py), 300 / 972 / 10 092 /
+// 99 372 triangles, reference streams, 1080p: 1 sample per call 6.5 -> 9.0, 11.1 -> 12.4, 9.5 -> 10.0, 7.2 -> 7.5 Grays/s;
+// 16 samples 7.6 -> 7.8, 13.3 -> 13.9, 11.3 -> 12.5, 8.9 -> 10.0; a grid 20 % larger or smaller than the resident blocks
+// loses 10-25 %.  range != 0: the contiguous pixels [b * range, (b + 1) * range).
+struct FusedBvhRange { uint32_t first, count, tile_stride; };
+__host__ __device__ inline FusedBvhRange fused_bvh_range(uint32_t pixel_count, uint32_t range, uint32_t b, uint32_t G) {
+	if (range != 0u) {
+		const uint32_t first = b * range;
+		return FusedBvhRange{ first, first < pixel_count ? (range < pixel_count - first ? range : pixel_count - first) : 0u, 64u };
+	}
+	const uint32_t n_tiles = (pixel_count + 63u) / 64u;
+	const uint32_t mine = b < n_tiles ? (n_tiles - b + G - 1u) / G : 0u;
+	uint32_t count = mine * 64u;
+	if (mine != 0u && b + (mine - 1u) * G == n_tiles - 1u) count -= n_tiles * 64u - pixel_count;      // the short tile is this block's last
+	return FusedBvhRange{ b * 64u, count, G * 64u };
+}
+
+// The block's pixels: the j-th is range_first + (j / 64) * tile_stride + j % 64, j < range_count (fused_bvh_range); *s_next is
 // zero and a block barrier passed on entry; s_stack is bvh_stack_depth x 256 words.  Every collective below is reached by
 // all lanes of a wave: the loop ends on ballots, never per lane.  n_rays / n_diffuse: this lane's counters (added to).
 template <bool STRIDED>
-__device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t range_first, uint32_t range_count,
+__device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t range_first, uint32_t range_count, uint32_t tile_stride,
                                                 uint32_t* s_stack, uint32_t* s_next, uint32_t& n_rays, uint32_t& n_diffuse) {
 	const FrameDev& f = c.f;
 	const uint32_t lane = threadIdx.x & 63u;
@@ -124,7 +144,7 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 				const uint32_t j = base + (uint32_t)__popcll(want_mask & ((1ull << lane) - 1ull));
 				if (base + n_want >= range_count) exhausted = true;          // wave-uniform: nothing left after this hand-out
 				if (want && j < range_count) {
-					li = range_first + j;
+					li = range_first + (j >> 6) * tile_stride + (j & 63u);      // tiles of 64 pixels, tile_stride apart (64: one contiguous range)
 					const uint32_t i = f.pixel_first + li;
 					px = i % (uint32_t)f.width; py = i / (uint32_t)f.width;
 					start = c.rng_io[li];

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 }
 
 // The fused engine on BVH scenes: persistent walks with in-register service of finished rays (pt_fused_bvh.hpp).
-// Block b owns the pixels [b * range, ...) of the frame's range and hands them to its lanes as they free up.
+// Block b owns the pixels fused_bvh_range(.., range, b, G) of the frame's range and hands them to its lanes as they free up.
 #ifndef PT_FUSED_BVH_WAVES
 #define PT_FUSED_BVH_WAVES 5
 #endif
@@ -607,9 +607,8 @@ __global__ __launch_bounds__(kBlock, PT_FUSED_BVH_WAVES) void k_fused_bvh(FrameD
 	               mean_first, n_samples, rng_io, mean_io };
 	__syncthreads();
 	uint32_t n_rays = 0, n_diffuse = 0;
-	const uint32_t range_first = blockIdx.x * range;
-	const uint32_t range_count = range_first < f.pixel_count ? min(range, f.pixel_count - range_first) : 0u;
-	fused_bvh_block<STRIDED>(c, range_first, range_count, s_stack, &s_next, n_rays, n_diffuse);
+	const FusedBvhRange mine = fused_bvh_range(f.pixel_count, range, blockIdx.x, gridDim.x);
+	fused_bvh_block<STRIDED>(c, mine.first, mine.count, mine.tile_stride, s_stack, &s_next, n_rays, n_diffuse);
 	if (stats) {
 		// as in k_fused: wave reduce -> block reduce in LDS -> one pair of global atomics per block into one of kStatsSlots partial sums
 		__shared__ unsigned long long s_cnt[2];
@@ -1263,28 +1262,16 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 #define PT_FUSED(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE, false>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
 	if (mode == 2 && !fused_bvh_plain()) {
-		// BVH scenes: the persistent form (pt_fused_bvh.hpp).  A block owns `range` pixels and hands them to its lanes as they
-		// free up; a lane also refills from its own pixel's remaining samples.  With many samples per call that alone keeps
-		// the lanes busy and short ranges (more blocks) balance best; with one sample per call -- the reference's frame loop --
-		// the pixel queue is all there is, and longer ranges win.  Measured at 1080p on 10 092 / 99 372 triangles, Mrays/s:
-		// 1 sample per call: 256 pixels 5140 / 3590, 512: 6330 / 4460, 832: 7440 / 5310, 1664: 7910 / 6040, 3328: 5400 / 3890
-		// (too few blocks); 16 samples: 9070 / 6490, 9260 / 6660, 8970 / 7140, 8940 / 6640, 5550 / 3950.  So the grid covers
-		// the machine's resident blocks once (one sample per call) or twice over, never with less than a pixel per lane.
-		// Small scenes want shorter ranges still: their walks are short (a block's last pixels drain quickly) and their pixels
-		// differ more in cost (a ray that grazes a large triangle tests much of the scene), so balance counts for more than the
-		// drain.  Measured after the graded inflation (tools/fused_range_sweep.py, 300 / 972 triangles, Mrays/s at 256 / 512 /
-		// 832 / 1664 pixels): 1 sample 5740 6770 5950 3550 / 7870 9870 11430 8070; 16 samples 7270 6100 4440 2830 / 12480 12950
-		// 10430 7290 (10 092 / 99 372 triangles: 1 sample 6070 7740 8900 9580 / 3980 5210 6230 7290; 16 samples 11880 11620
-		// 11410 11230 / 8190 8460 8730 8370).  Short ranges are whole blocks' worth of pixels: 320 or 576 leave a block one
-		// wave's worth for its last hand-out and lose 15-20 % against 256 and 512.  Hence the caps below 640 / 4096 triangles.
-		const char* env_range_s = std::getenv("PT_FUSED_RANGE");                                       // measurement knob
-		const uint32_t env_range = env_range_s ? (uint32_t)std::atoi(env_range_s) : 0u;
+		// BVH scenes: the persistent form (pt_fused_bvh.hpp).  A block hands its pixels to its lanes as they free up; a lane
+		// also refills from its own pixel's remaining samples.  The pixels are dealt out in interleaved 64-pixel tiles over
+		// exactly the blocks the machine holds at once (fused_bvh_range: measurements there), at least a block's worth each.
+		// Contiguous ranges had to be tuned per scene size and samples per call and still lost (history: DESIGN 4.2);
+		// PT_FUSED_RANGE=<pixels> in the environment brings them back for measurements.
+		const char* env_range_s = std::getenv("PT_FUSED_RANGE");
+		const uint32_t range = env_range_s ? (uint32_t)std::max(1, std::atoi(env_range_s)) : 0u;
 		const uint32_t resident = (uint32_t)grid_for((size_t)1 << 40) / 8u * (uint32_t)PT_FUSED_BVH_WAVES;      // CUs x blocks per CU
-		const uint32_t fill = n_samples >= 2u ? 2u : 1u;
-		const uint32_t cap = si.n_tris < 640u ? (n_samples >= 2u ? 256u : 512u) : si.n_tris < 4096u ? (n_samples >= 2u ? 512u : 832u) : 0xFFFFFFFFu;
-		const uint32_t range = env_range ? std::max(env_range, 1u)
-		                                 : std::max<uint32_t>(kBlock, std::min<uint32_t>(cap, (uint32_t)(((size_t)frame->pixel_count / ((size_t)resident * fill) + 63) / 64 * 64)));
-		dim3 pgrid((unsigned)(((size_t)frame->pixel_count + range - 1) / range));
+		dim3 pgrid(range ? (unsigned)(((size_t)frame->pixel_count + range - 1) / range)
+		                 : (unsigned)std::max<size_t>(1, std::min<size_t>(resident, ((size_t)frame->pixel_count + kBlock - 1) / kBlock)));
 #define PT_FUSED_BVH(STR) hipLaunchKernelGGL((k_fused_bvh<STR>), pgrid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, range, rng, (float4*)mean, (unsigned long long*)stats)
 		if (strided) PT_FUSED_BVH(true); else PT_FUSED_BVH(false);

@@ -40,7 +40,9 @@ int main(int argc, char** argv) {
 	pt_frame fr;
 	std::memcpy(&fr, frame_v.data(), sizeof(fr));
 	const uint32_t frame_first = (uint32_t)std::atol(argv[3]), mean_first = (uint32_t)std::atol(argv[4]), n_samples = (uint32_t)std::atol(argv[5]);
-	const uint32_t range = (uint32_t)std::atol(argv[6]);
+	// pixels per block: a number = contiguous ranges of that many; iG = interleaved tiles over G blocks (fused_bvh_range)
+	const bool interleaved = argv[6][0] == 'i';
+	const uint32_t range = interleaved ? 0u : (uint32_t)std::atol(argv[6]);
 	const int lanes = argc > 8 ? std::atoi(argv[8]) : 64;                  // < 64: partial waves (a block of 4 x lanes threads)
 	unsigned char* blob = (unsigned char*)std::malloc(blob_v.size());
 	std::memcpy(blob, blob_v.data(), blob_v.size());
@@ -105,7 +107,7 @@ int main(int argc, char** argv) {
 		return 0;
 	}
 	const BvhView bv = make_bvh_view(blob, n_tris, n_mats, f.origin);
-	const uint32_t G = (N + range - 1) / range;
+	const uint32_t G = interleaved ? (uint32_t)std::atol(argv[6] + 1) : (N + range - 1) / range;
 	gridDim.x = G;
 	for (uint32_t blk = 0; blk < G; blk++) {
 		blockIdx.x = blk;
@@ -121,10 +123,10 @@ int main(int argc, char** argv) {
 					threadIdx.x = w * 64 + (unsigned)l;
 					t_wave = &waves[w];
 					FusedBvhCtx c{ f, bv, tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_stride, mean_first, n_samples, rng, mean };
-					const uint32_t first = blk * range, count = first < N ? std::min(range, N - first) : 0u;
+					const FusedBvhRange mine = fused_bvh_range(N, range, blk, G);
 					uint32_t n_rays = 0, n_diffuse = 0;
-					if (strided) fused_bvh_block<true>(c, first, count, s_stack, &s_next, n_rays, n_diffuse);
-					else fused_bvh_block<false>(c, first, count, s_stack, &s_next, n_rays, n_diffuse);
+					if (strided) fused_bvh_block<true>(c, mine.first, mine.count, mine.tile_stride, s_stack, &s_next, n_rays, n_diffuse);
+					else fused_bvh_block<false>(c, mine.first, mine.count, mine.tile_stride, s_stack, &s_next, n_rays, n_diffuse);
 					cnt[2 * threadIdx.x] = n_rays; cnt[2 * threadIdx.x + 1] = n_diffuse;
 				});
 		for (auto& t : th) t.join();

@@ -20,7 +20,7 @@ def bits(a):
 
 
 def run(pt, oracle, tmp_path, scene, w, h, spp, depth=10, cam=None, rng_mode=0, stride=35, shading=0, frame_first=0, mean_first=0,
-        pixel_first=0, pixel_count=None, pixels_per_block=1024, lanes=64):
+        pixel_first=0, pixel_count=None, pixels_per_block="i3", lanes=64):
     V, T, M = scene
     c = oracle.camera_corners(cam or oracle.default_camera(), np.float32(w) / np.float32(h))
     f4 = lambda v: pt.Float4(v.x, v.y, v.z, v.w)
@@ -41,10 +41,12 @@ def run(pt, oracle, tmp_path, scene, w, h, spp, depth=10, cam=None, rng_mode=0, 
 
 @needs_binary
 @pytest.mark.parametrize("n_tris,w,h,spp,per_block,lanes", [(700, 48, 30, 3, 1024, 64), (2500, 40, 24, 2, 256, 64), (700, 37, 19, 4, 300, 64),
-                                                            (1500, 33, 21, 2, 512, 37)])
+                                                            (1500, 33, 21, 2, 512, 37), (700, 48, 30, 3, "i2", 64), (1500, 37, 19, 2, "i5", 64),
+                                                            (700, 33, 21, 2, "i40", 64), (2500, 40, 24, 2, "i3", 37)])
 def test_reference_streams(pt, oracle, tmp_path, n_tris, w, h, spp, per_block, lanes):
-    """sequential streams (a pixel's samples in order in one lane); blocks of 256..1024 pixels, a range that is no multiple of
-    the block, 37-lane waves"""
+    """sequential streams (a pixel's samples in order in one lane); blocks of 256..1024 contiguous pixels, a range that is no
+    multiple of the block, 37-lane waves; iG = what the launcher does: interleaved 64-pixel tiles over G blocks
+    (fused_bvh_range) -- a short last tile (48x30 = 22.5 tiles, 37x19 = 10.98), more blocks than tiles (33x21 = 11 tiles over 40)"""
     V, T, M = scenes.synthetic_scene(n_tris)
     ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, spp=spp), scene=oracle.make_scene(V, T, M))
     img, rng, rays = run(pt, oracle, tmp_path, (V, T, M), w, h, spp, pixels_per_block=per_block, lanes=lanes)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """k_fused_bvh (the fused engine's persistent form on BVH scenes): pixels per block (PT_FUSED_RANGE; 0 = the launcher's choice)
-against scene size and samples per call, reference streams, 1080p; Mrays/s (device time)."""
+against scene size and samples per call, reference streams, 1080p; Mrays/s (device time).
+0 = the launcher's own choice: interleaved tiles over the resident blocks (fused_bvh_range in pt_fused_bvh.hpp)."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
