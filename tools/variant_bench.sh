@@ -1,3 +1,6 @@
+#!/bin/bash
+# Same-box A/B of library variants (tools/build_variant.sh) on the 10 092-triangle bench, both engines:
+#   VARIANTS="base name ..." bash tools/variant_bench.sh
 for v in $VARIANTS; do
   for w in c4_10k; do
   for e in wavefront fused; do
