@@ -6,15 +6,19 @@
 //
 // Why that needs care: ray_triangle accepts when the COMPUTED u, v satisfy 0<=u, 0<=v, u+v<=1, and
 // those carry rounding error amplified by f = 1/det.  The reference's own culling gives the handle:
-// an accepted hit has det >= EPSILON (Functions.cuh:72).  With eps = 2^-24,
-//     |du| * |e0|  <~  c * eps * |d| * |e0||e1| * (|s| + |e0|) / det   <=  c * eps * |e0||e1| * S / EPSILON
-// (|d| <= 1 for every ray this tracer makes, S bounds |origin - vertex| + edge length), likewise for v
-// and for t.  So the true ray/plane intersection of an accepted hit lies within
-//     delta_i = kappa_i * S,   kappa_i = 16 * eps * |e0||e1| / EPSILON
-// (a term-by-term bound gives 7 eps (|s| + |e0|) |d||e0||e1| / det_true with det_true >= 0.64 EPSILON for
-// |e0||e1| <= 1, i.e. c = 11; 16 leaves head-room, and triangles with |e0||e1| >> 1 get boxes larger than
-// the scene, which is what their unbounded error needs).
-// of triangle i.  Each child box stores the max kappa of its subtree; the traversal inflates the box
+// an accepted hit has det >= EPSILON (Functions.cuh:72).  Term by term, with eps = 2^-24 the unit roundoff, D = |d||e0||e1|
+// and det_true = D sin(phi) |cos(theta)| (phi between the edges, theta between ray and normal):
+//     cross product   |dh| <= 2.83 eps |d||e1|           three-term dot product   <= 3 eps |a||b|          s = o - v0   <= eps |s|
+//     det             |ddet| <= 5.83 eps D               numerators of u, v, t    <= 6.83 eps |s| D / |e0| (resp. |e1|, |d|)
+//     |du| |e0|  <=  eps (6.83 |s| + 5.83 |e0|) D / det_true,    |dv| |e1| likewise with |e1|,    |dt| |d| likewise with |t||d|
+// The true ray/plane intersection of an accepted hit is the computed (u, v) point -- inside the triangle -- moved by
+// du e0 + dv e1, so it lies within |du||e0| + |dv||e1| <= 13.7 eps S D / det_true of the triangle, S >= |origin - vertex| +
+// edge length (and |dt||d| obeys the same bound: |s| + |t||d| <= 2 S).  An accepted hit has det_true >= EPSILON - |ddet| >=
+// 0.65 EPSILON for D <= 1, hence
+//     delta_i = kappa_i * S,   kappa_i = 24 * eps * |e0||e1| / EPSILON        (13.7 / 0.65 = 21; |d| <= 1 for every ray this tracer makes)
+// (round 1 and most of round 2 ran with 16: the bound for ONE of u, v with head-room -- no test ever found a hit outside
+// it, rounding errors do not line up, but the claim is a bound; triangles with |e0||e1| >> 1 get boxes larger than the
+// scene, which is what their unbounded error needs).  Each child box stores the max kappa of its subtree; the traversal inflates the box
 // by kappa * S + a relative slack for its own arithmetic, and widens the ray interval by the root's
 // delta.  Small triangles (the 10^4..10^5-triangle scenes this is for) get small inflations
 // (|e0||e1| = 2e-4 -> delta = 3e-4 * S); large ones get large boxes, which only costs time.
@@ -37,7 +41,7 @@ namespace ptbvh {
 constexpr uint32_t kLeafSize = PT_BVH_LEAF;        // == ptd::kBvhLeafSize (pt_device.hpp: the traversal stack is sized from it)
 static_assert(kLeafSize >= 1 && kLeafSize <= 8, "leaf code holds count - 1 in 3 bits");
 constexpr float kEps32 = 5.9604645e-8f;            // 2^-24
-constexpr float kKappaScale = 16.0f * kEps32 / 0.000001f;
+constexpr float kKappaScale = 24.0f * kEps32 / 0.000001f;
 
 // What the builder works with: the two children's boxes live in the parent.
 struct Node {
@@ -69,26 +73,26 @@ struct LeafTri { float f[16]; };
 // The worst case kappa_i * S above (det barely above EPSILON) belongs to a GRAZING ray: det_true = |d| |e0||e1| sin(phi)
 // |cos(theta)| (phi between the edges, theta between ray and normal).  If |cos(theta)| >= rho and sin(phi) >= kSinFloor
 // the same term-by-term bound reads
-//     delta <= 7 * eps * S / (rho * sin(phi))  <=  kKappaRho / rho * S,     kKappaRho = 11 * eps / kSinFloor
+//     delta <= 13.7 * eps * S / (rho * sin(phi))  <=  kKappaRho / rho * S,     kKappaRho = 16 * eps / kSinFloor
 // whatever the triangle's size (no EPSILON in it: det_true is bounded directly; the computed determinant's own relative
-// error e = 4 eps / (rho sin(phi)) scales the bound by 1 / (1 - e): 1 % at rho = kRhoMin, inside the 11-for-7 head-room,
-// which would last down to rho = 3e-6) -- at rho = 0.02 that is 1.3e-4 * S against
-// 7e-3 * S for the quads of the 10 092-triangle scene, whose boxes the worst case makes half as wide again.
+// error e = 5.83 eps / (rho sin(phi)) scales the bound by 1 / (1 - e): 1.4 % at rho = kRhoMin, inside the 16-for-13.7 head-room,
+// which would last down to rho = 1e-5) -- at rho = 0.02 that is 1.9e-4 * S against
+// 1e-2 * S for the quads of the 10 092-triangle scene, whose boxes the worst case makes half as wide again.
 // So the builder sorts the triangles' planes (normals, sign-agnostic) into at most kMaxClasses classes, each a cone of
 // half-angle h around an axis, stored as {axis * cos(h), sin(h)} (with margins): for a ray at angle beta to the plane
 // perpendicular to the axis, sin(beta) = |dhat . axis|, and its angle to any plane of the class is at least beta - h, so
 //     |cos(theta)| >= sin(beta - h) >= |dhat . axis| cos(h) - sin(h)  =: rho_k      (one dot product and a subtraction)
 // for EVERY triangle of the class.  In a scene whose triangles all belong to a class, rho = min_k rho_k bounds how close
 // to grazing a ray comes to anything, and the ray inflates every box by
-//     min(worst case, kKappaRho / rho * S),     kKappaRho = 11 * eps / kSinFloor
-// -- graded, not a two-way choice: in an axis-aligned room 94 % of the rays have rho >= 0.02 (1.3e-4 * S or less), 4.5 % lie
-// between 0.005 and 0.02 (at most 5e-4 * S), and only what lies below kRhoMin (3 rays in 10 000) keeps the worst case -- which on scenes
+//     min(worst case, kKappaRho / rho * S),     kKappaRho = 16 * eps / kSinFloor
+// -- graded, not a two-way choice: in an axis-aligned room 94 % of the rays have rho >= 0.02 (1.9e-4 * S or less), 4.5 % lie
+// between 0.005 and 0.02 (at most 8e-4 * S), and only what lies below kRhoMin (3 rays in 10 000) keeps the worst case -- which on scenes
 // of a few hundred LARGE triangles is larger than the boxes themselves (300 triangles: 0.15 * S), so every ray that fell
 // back to it tested the whole scene, holding its wave for the time of twenty (measured with the cut at 1e-3, 3 rays in
 // 1000: the fused engine ran 192..588 triangles at 4.0..6.5 Grays/s between 9.1 at 108 and 9.6 at 972).  Rays of a scene with slivers or more plane directions than classes keep the worst case.
 constexpr float kRhoMin = 1e-4f;                   // == ptd::kBvhRhoMin: below this |cos(ray, normal)| bound a ray counts as grazing (worst case)
 constexpr float kSinFloor = 0.25f;                 // triangles whose edges e0, e1 are closer to parallel than this are never classified
-constexpr float kKappaRho = 11.0f * kEps32 / kSinFloor;      // == ptd::kBvhKappaRho
+constexpr float kKappaRho = 16.0f * kEps32 / kSinFloor;      // == ptd::kBvhKappaRho
 constexpr uint32_t kMaxClasses = 8;                // == ptd::kBvhMaxClasses
 constexpr double kClassAngle = 0.14;               // radians (8 degrees): how far a normal may be from its class's axis
 

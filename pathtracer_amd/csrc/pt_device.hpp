@@ -201,7 +201,7 @@ __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block
 constexpr uint32_t kBvhClassBytes = 192;    // pt_bvh.hpp ClassBlock
 constexpr uint32_t kBvhMaxClasses = 8;      // == ptbvh::kMaxClasses
-constexpr float kBvhKappaRho = 11.0f * 5.9604645e-8f / 0.25f;     // == ptbvh::kKappaRho: inflation per unit of S, times the ray's rho (pt_bvh.hpp, normal classes)
+constexpr float kBvhKappaRho = 16.0f * 5.9604645e-8f / 0.25f;     // == ptbvh::kKappaRho: inflation per unit of S, times the ray's rho (pt_bvh.hpp, normal classes)
 constexpr float kBvhRhoMin = 1e-4f;                              // == ptbvh::kRhoMin
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
