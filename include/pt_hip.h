@@ -74,6 +74,11 @@ enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
  * together.  Same results bit for bit; faster where paths differ in length (deep scenes), slower where they do not (the
  * reference's own scene).  The plugin sets it after measuring both forms (pt_plugin.h, engine). */
 #define PT_FRAME_OUT_OF_STEP 4u
+/* PT_FRAME_DEFER_FOLD (pt_hip_render_fused): the call leaves its ray counters in the partial sums of the statistics array
+ * (pt_hip.h, "Counters") and the caller folds them with pt_hip_fold_stats once the work is done -- for callers that run several
+ * render calls on DIFFERENT streams side by side over one statistics array (the plugin's sample split: a fold zeroes the
+ * partial sums, which must not happen under another stream's running kernel).  No counterpart in the reference. */
+#define PT_FRAME_DEFER_FOLD 8u
 
 /* Which kernels execute a render call. */
 enum { PT_ENGINE_WAVEFRONT = 0, PT_ENGINE_FUSED = 1, PT_ENGINE_AUTO = 2 };     /* AUTO: pt_plugin.h (the plugin measures and picks) */
@@ -129,6 +134,7 @@ int pt_hip_stream_synchronize(void* stream);
 int pt_hip_event_create(void** event);
 int pt_hip_event_destroy(void* event);
 int pt_hip_event_record(void* event, void* stream);
+int pt_hip_stream_wait_event(void* stream, void* event);      /* work queued on `stream` after this call starts once `event` has happened */
 int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* waits for `stop` */
 
 /* ---- scene: Vertex/Triangle/Material arrays (Structures.cuh:43-69, upload PathTracer.cu:48-77)
@@ -251,6 +257,8 @@ int pt_hip_render_wavefront_noalloc(const pt_frame* frame, const void* scene_blo
 int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                         uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
                         uint32_t* rng, void* mean, uint64_t* stats, void* stream);
+/* Folds the partial sums render calls with PT_FRAME_DEFER_FOLD left behind into stats[0..1] (and zeroes them). */
+int pt_hip_fold_stats(uint64_t* stats, void* stream);
 
 /* Sample-split combine (no reference counterpart: the reference is single-GPU).
  * out = (fixed-order pairwise tree sum of `shards` means laid out shard-major) * 1/shards. */

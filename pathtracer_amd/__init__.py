@@ -30,6 +30,7 @@ PT_SHADING_REFERENCE, PT_SHADING_EXTENDED = 0, 1
 PT_FRAME_FAST_DIV = 1
 PT_FRAME_SCENE_BVH = 2
 PT_FRAME_OUT_OF_STEP = 4
+PT_FRAME_DEFER_FOLD = 8
 PT_MAX_DEPTH = 32
 PT_BVH_DEFAULT_MIN_TRIANGLES = 96
 PT_STATS_PUBLIC_WORDS = 64
@@ -155,6 +156,8 @@ SYMBOLS = {
     "pt_hip_event_create": (C.c_int, [C.POINTER(_VP)]),
     "pt_hip_event_destroy": (C.c_int, [_VP]),
     "pt_hip_event_record": (C.c_int, [_VP, _VP]),
+    "pt_hip_stream_wait_event": (C.c_int, [_VP, _VP]),
+    "pt_hip_fold_stats": (C.c_int, [_VP, _VP]),
     "pt_hip_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
     "pt_hip_set_bvh_threshold": (C.c_int, [_U32]),
     "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),

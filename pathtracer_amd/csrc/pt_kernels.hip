@@ -848,6 +848,11 @@ int pt_hip_event_record(void* event, void* stream) {
 	HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
 	return PT_OK;
 }
+int pt_hip_stream_wait_event(void* stream, void* event) {
+	if (!event) return fail(PT_ERR_INVALID, "event is null");
+	HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+	return PT_OK;
+}
 int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
 	if (!start || !stop || !ms) return fail(PT_ERR_INVALID, "event_elapsed_ms: null pointer");
 	HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
@@ -1287,7 +1292,14 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	else if (strided) { if (mode == 2) PT_FUSED(true, 2); else if (mode == 1) PT_FUSED(true, 1); else PT_FUSED(true, 0); }
 	else { if (mode == 2) PT_FUSED(false, 2); else if (mode == 1) PT_FUSED(false, 1); else PT_FUSED(false, 0); }
 #undef PT_FUSED
-	if (stats) hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (unsigned long long*)stats);
+	if (stats && !(frame->flags & PT_FRAME_DEFER_FOLD)) hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (unsigned long long*)stats);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+int pt_hip_fold_stats(uint64_t* stats, void* stream) {
+	if (!stats) return fail(PT_ERR_INVALID, "fold_stats: null pointer");
+	hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)stats);
 	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
