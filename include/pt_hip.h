@@ -257,6 +257,16 @@ int pt_hip_render_wavefront_noalloc(const pt_frame* frame, const void* scene_blo
 int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                         uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
                         uint32_t* rng, void* mean, uint64_t* stats, void* stream);
+/* pt_hip_render_fused for n_shards sample shards of one frame at once (pt_plugin.h, PT_SPLIT_SAMPLE; no counterpart in the
+ * reference): shard k takes the samples that start at frame_first[k] and accumulates into the mean mean_pitch_pixels pixels
+ * after shard k - 1's; every shard continues at mean_first.  The same results, bit for bit, as n_shards calls of
+ * pt_hip_render_fused -- which is what happens for BVH scenes and with PT_FRAME_OUT_OF_STEP; otherwise ONE launch in which a
+ * pixel's coordinates, culling masks and stream word and a block's tables are set up once for all shards.  Several shards
+ * need PT_RNG_STRIDED (the stream words are only read).  n_shards <= PT_FUSED_MAX_SHARDS. */
+#define PT_FUSED_MAX_SHARDS 16
+int pt_hip_render_fused_shards(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                               const uint32_t* frame_first, uint32_t n_shards, uint32_t mean_first, uint32_t n_samples,
+                               uint32_t* rng, void* mean, size_t mean_pitch_pixels, uint64_t* stats, void* stream);
 /* Folds the partial sums render calls with PT_FRAME_DEFER_FOLD left behind into stats[0..1] (and zeroes them). */
 int pt_hip_fold_stats(uint64_t* stats, void* stream);
 

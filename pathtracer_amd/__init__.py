@@ -158,6 +158,7 @@ SYMBOLS = {
     "pt_hip_event_record": (C.c_int, [_VP, _VP]),
     "pt_hip_stream_wait_event": (C.c_int, [_VP, _VP]),
     "pt_hip_fold_stats": (C.c_int, [_VP, _VP]),
+    "pt_hip_render_fused_shards": (C.c_int, [_FRAMEP, _VP, _U32, _U32, C.POINTER(_U32), _U32, _U32, _U32, _VP, _VP, _SZ, _VP, _VP]),
     "pt_hip_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
     "pt_hip_set_bvh_threshold": (C.c_int, [_U32]),
     "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),

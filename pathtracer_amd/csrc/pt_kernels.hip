@@ -145,7 +145,8 @@ void host_jump_matrix(uint64_t k, uint32_t cols[32]) {
 	}
 }
 
-struct JumpMat { uint32_t cols[32]; };
+template <int N> struct JumpMats { uint32_t cols[32 * N]; };      // N GF(2) jump matrices, 32 columns each (kernel arguments)
+using JumpMat = JumpMats<1>;
 
 // SceneHeader::flags bit 0 (wave-uniform scalar load): pt_device.hpp, ray_triangle
 __device__ __forceinline__ bool scene_det_bounded(const unsigned char* scene) {
@@ -442,12 +443,18 @@ __global__ __launch_bounds__(kBlock) void k_fill_f32(float* __restrict__ dst, fl
 #ifndef PT_FUSED_OOS_WAVES
 #define PT_FUSED_OOS_WAVES 8
 #endif
-template <bool STRIDED, int SCENE, bool OUT_OF_STEP>
+// MAXS > 1 (strided streams, in step): ONE launch renders n_shards <= MAXS sample shards of the frame (pt_plugin.h,
+// PT_SPLIT_SAMPLE) -- shard k starts its streams at first.cols[32 k ..] and accumulates into the mean mean_pitch pixels
+// after shard k - 1's -- so that a pixel's coordinates, culling masks and stream word, and a block's tables, are set up
+// once for all of them instead of once per shard and launch.  MAXS == 1: n_shards and mean_pitch are not looked at.
+template <bool STRIDED, int SCENE, bool OUT_OF_STEP, int MAXS = 1>
 __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS_WAVES : 8) void k_fused(FrameDev f, const unsigned char* __restrict__ scene,
-                                                  uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
-                                                  uint32_t mean_first, uint32_t n_samples,
+                                                  uint32_t n_tris, uint32_t n_mats, JumpMats<MAXS> first, JumpMat per_sample,
+                                                  uint32_t mean_first, uint32_t n_samples, uint32_t n_shards, uint32_t mean_pitch,
                                                   uint32_t* __restrict__ rng_io, float4* __restrict__ mean_io,
                                                   unsigned long long* __restrict__ stats) {
+	static_assert(MAXS == 1 || (STRIDED && !OUT_OF_STEP && SCENE != 2), "several shards per launch: strided streams, in step, no BVH");
+	const uint32_t ns = MAXS > 1 ? n_shards : 1u;
 	constexpr bool SCENE_LDS = SCENE == 1;
 	constexpr bool BVH = SCENE == 2;
 	extern __shared__ float4 s_scene[];
@@ -455,10 +462,13 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 	uint32_t* s_stack = reinterpret_cast<uint32_t*>(s_scene);     // BVH: the dynamic LDS is the traversal stack, bvh_stack_depth x 256 words
 	// STRIDED: the two jump matrices are read from LDS, not kept in 64 SGPRs across the pixel loop (106 SGPRs admit
 	// 6 blocks per CU, 74 admit 8)
-	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1];
+	__shared__ uint32_t s_first[STRIDED ? 32 * MAXS : 1], s_per_sample[STRIDED ? 32 : 1];
 	// ... and step^stride, taken once per sample whose draws differ from the stride, as a byte table (4 lookups instead of 32 columns)
 	__shared__ uint32_t s_stride[STRIDED ? 1024 : 1];
-	if (STRIDED && threadIdx.x < 32) { s_first[threadIdx.x] = first.cols[threadIdx.x]; s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x]; }
+	if (STRIDED) {
+		for (uint32_t t = threadIdx.x; t < 32u * ns; t += kBlock) s_first[t] = first.cols[t];
+		if (threadIdx.x < 32) s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x];
+	}
 	if (STRIDED) { __syncthreads(); build_stride_table(s_per_sample, s_stride); }
 	stage_jump31(s_jump);
 	const bool det_bounded = scene_det_bounded(scene);
@@ -482,7 +492,8 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 	for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < f.pixel_count; li += gridDim.x * kBlock) {
 		uint32_t i = f.pixel_first + li;
 		uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
-		uint32_t start = rng_io[li];
+		const uint32_t word = rng_io[li];
+		uint32_t start = word;
 		if (STRIDED) start = mat_apply_lds(s_first, start);
 		uint32_t rng = start;
 		float4 m = mean_io[li];
@@ -496,6 +507,12 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 		// the triangles this wave's pixels can see at all (none of the lanes here is out of range: the loop bound holds for li)
 		unsigned long long need = ~0ull;
 		if (use_prim) need = primary_need_mask(f, px, py, true, tris, s_prim, n_tris);
+		for (uint32_t shard = 0; shard < ns; shard++) {
+		if (MAXS > 1 && shard != 0u) {
+			start = mat_apply_lds(s_first + 32u * shard, word);
+			rng = start;
+			m = mean_io[(size_t)shard * mean_pitch + li];
+		}
 		for (uint32_t s = 0; s < n_samples; s++) {
 			Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
 			Vec3 d = primary_direction(f, px, py, rng);
@@ -552,7 +569,8 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 				start = rng;
 			}
 		}
-		mean_io[li] = m;
+		mean_io[(MAXS > 1 ? (size_t)shard * mean_pitch : (size_t)0) + li] = m;
+		}
 		if (!STRIDED) rng_io[li] = rng;
 	}
 	if (stats) {
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 			unsigned long long* slot = stats + PT_STATS_PUBLIC_WORDS + (size_t)(blockIdx.x % kStatsSlots) * kStatsSlotWords;
 			atomicAdd(&slot[0], s_cnt[0]);
 			atomicAdd(&slot[1], s_cnt[1]);
-			if (blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_samples * f.pixel_count);
+			if (blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_samples * f.pixel_count * ns);
 		}
 	}
 }
@@ -1265,7 +1283,7 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	// persistent grid sized for 8 leaves a one-third-full tail round.
 	dim3 grid((unsigned)(((size_t)frame->pixel_count + kBlock - 1) / kBlock)), block(kBlock);
 #define PT_FUSED(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE, false>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
-	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
+	mean_first, n_samples, 1u, 0u, rng, (float4*)mean, (unsigned long long*)stats)
 	if (mode == 2 && !fused_bvh_plain()) {
 		// BVH scenes: the persistent form (pt_fused_bvh.hpp).  A block hands its pixels to its lanes as they free up; a lane
 		// also refills from its own pixel's remaining samples.  The pixels are dealt out in interleaved 64-pixel tiles over
@@ -1284,7 +1302,7 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	}
 	else if (mode != 2 && ((frame->flags & PT_FRAME_OUT_OF_STEP) || std::getenv("PT_FUSED_OUT_OF_STEP"))) {      // (the environment: measurement knob)
 #define PT_FUSED_OOS(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE, true>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
-	mean_first, n_samples, rng, (float4*)mean, (unsigned long long*)stats)
+	mean_first, n_samples, 1u, 0u, rng, (float4*)mean, (unsigned long long*)stats)
 		if (strided) { if (mode == 1) PT_FUSED_OOS(true, 1); else PT_FUSED_OOS(true, 0); }
 		else { if (mode == 1) PT_FUSED_OOS(false, 1); else PT_FUSED_OOS(false, 0); }
 #undef PT_FUSED_OOS
@@ -1292,6 +1310,41 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	else if (strided) { if (mode == 2) PT_FUSED(true, 2); else if (mode == 1) PT_FUSED(true, 1); else PT_FUSED(true, 0); }
 	else { if (mode == 2) PT_FUSED(false, 2); else if (mode == 1) PT_FUSED(false, 1); else PT_FUSED(false, 0); }
 #undef PT_FUSED
+	if (stats && !(frame->flags & PT_FRAME_DEFER_FOLD)) hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (unsigned long long*)stats);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+int pt_hip_render_fused_shards(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                               const uint32_t* frame_first, uint32_t n_shards, uint32_t mean_first, uint32_t n_samples,
+                               uint32_t* rng, void* mean, size_t mean_pitch_pixels, uint64_t* stats, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!scene_blob || !rng || !mean || !frame_first) return fail(PT_ERR_INVALID, "render_fused_shards: null pointer");
+	if (n_shards == 0 || n_shards > PT_FUSED_MAX_SHARDS) return fail(PT_ERR_LIMIT, "render_fused_shards: 1 .. PT_FUSED_MAX_SHARDS shards");
+	if (n_shards > 1 && frame->rng_mode != PT_RNG_STRIDED) return fail(PT_ERR_INVALID, "render_fused_shards: several shards need PT_RNG_STRIDED (a sequential stream belongs to one accumulation)");
+	if (n_shards > 1 && (mean_pitch_pixels < frame->pixel_count || mean_pitch_pixels > 0xFFFFFFFFull)) return fail(PT_ERR_INVALID, "render_fused_shards: the means must be at least pixel_count pixels apart");
+	if (n_samples == 0 || frame->pixel_count == 0) return PT_OK;
+	SceneInfo si = scene_info(frame, n_triangles, n_materials);
+	const int mode = scene_has_bvh(si) ? 2 : shade_scene_in_lds(si) ? 1 : 0;
+	if (n_shards == 1 || mode == 2 || (frame->flags & PT_FRAME_OUT_OF_STEP) || std::getenv("PT_FUSED_OUT_OF_STEP") || std::getenv("PT_SPLIT_ONE_LAUNCH_OFF")) {
+		// forms with no several-shards kernel (BVH scenes, out of step): one launch per shard, the same results
+		for (uint32_t k = 0; k < n_shards; k++)
+			if (int rc = pt_hip_render_fused(frame, scene_blob, n_triangles, n_materials, frame_first[k], mean_first, n_samples, rng,
+			                                 (char*)mean + (size_t)k * mean_pitch_pixels * sizeof(float4), stats, stream)) return rc;
+		return PT_OK;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	FrameDev f = to_dev(*frame);
+	JumpMats<PT_FUSED_MAX_SHARDS> first{};
+	JumpMat per{};
+	for (uint32_t k = 0; k < n_shards; k++) host_jump_matrix((uint64_t)frame_first[k] * frame->stride, first.cols + 32u * k);
+	host_jump_matrix(frame->stride, per.cols);
+	size_t lds_bytes = (mode == 1 ? shade_lds_bytes(si) : 0) + (si.n_tris <= kPrimMaxTris ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
+	dim3 grid((unsigned)(((size_t)frame->pixel_count + kBlock - 1) / kBlock)), block(kBlock);
+#define PT_FUSED_SHARDS(MODE) hipLaunchKernelGGL((k_fused<true, MODE, false, PT_FUSED_MAX_SHARDS>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
+	mean_first, n_samples, n_shards, (uint32_t)mean_pitch_pixels, rng, (float4*)mean, (unsigned long long*)stats)
+	if (mode == 1) PT_FUSED_SHARDS(1); else PT_FUSED_SHARDS(0);
+#undef PT_FUSED_SHARDS
 	if (stats && !(frame->flags & PT_FRAME_DEFER_FOLD)) hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (unsigned long long*)stats);
 	HIP_TRY(hipGetLastError());
 	return PT_OK;

@@ -699,9 +699,21 @@ private:
 		_candInFlight = cand;
 		_imageCurrent = false;
 		PT_TRY(pt_hip_event_record(_evStart, _stream));
-		// Several local shards through the fused engine (strided streams: the launches only READ the stream words, and each
-		// writes a mean of its own): side by side on up to four streams.  On one stream a launch starts when the one before
-		// has drained; measured (tools/split_cost.py, 8 shards x 8 samples at 1080p) that is 0.06 ms per launch of a 1.0 ms step.
+		// Several local shards through the fused engine (strided streams: the stream words are only READ, and each shard
+		// writes a mean of its own).  Brute-force scenes in step: all of them in ONE launch (pt_hip_render_fused_shards) --
+		// a launch per shard costs 0.06 ms of a 1.0 ms step (tools/split_cost.py, 1080p, 8 shards x 8 samples).
+		const bool one_launch = engine == PT_ENGINE_FUSED && _localShards > 1 && _localShards <= PT_FUSED_MAX_SHARDS && f.rng_mode == PT_RNG_STRIDED &&
+		                        !(f.flags & (PT_FRAME_SCENE_BVH | PT_FRAME_OUT_OF_STEP));
+		if (one_launch) {
+			uint32_t firsts[PT_FUSED_MAX_SHARDS];
+			for (uint32_t j = 0; j < _localShards; j++) firsts[j] = _opt.sample_offset + (_opt.split_rank + j * _ranks) * PT_SHARD_SPAN + _frameNumber;
+			PT_TRY(pt_hip_render_fused_shards(&f, _dev.scene, _nTris, _nMats, firsts, _localShards, _frameNumber, samples, _dev.rng, _dev.mean, _pitch, _dev.stats, _stream));
+			PT_TRY(pt_hip_event_record(_evStop, _stream));
+			_inFlightSamples = samples;
+			return PT_OK;
+		}
+		// ... otherwise (BVH scenes, out of step) a launch per shard, side by side on up to four streams: on one stream a
+		// launch starts when the one before has drained
 		const bool spread = engine == PT_ENGINE_FUSED && _localShards > 1 && f.rng_mode == PT_RNG_STRIDED && !std::getenv("PT_SPLIT_ONE_STREAM");
 		if (spread) {
 			if (!_evFork) {

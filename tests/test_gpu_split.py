@@ -220,3 +220,42 @@ def test_candidates_are_measured_again_when_the_samples_per_call_change(pt, orac
         img = tr.readback()
     ref, _, _, _ = oracle.render(oracle.params(w, h, depth=12, spp=3 + 2 + 32), scene=oracle.make_scene(V, T, M))
     assert_bit_equal(img, ref, "all materials, fused engine across two measurements")
+
+
+@pytest.mark.parametrize("scene_name,shards,flags", [("default", 8, 0), ("materials", 4, 0), ("materials", 3, "oos"), ("synthetic700", 4, 0), ("default", 16, 0)])
+def test_several_shards_in_one_launch_equal_a_launch_per_shard(pt, oracle, scene_name, shards, flags):
+    """pt_hip_render_fused_shards through the C-ABI against one pt_hip_render_fused per shard: every shard's running mean and the
+    counters bit for bit, on two calls in a row (the second continues the means).  Brute-force scenes take the one-launch kernel,
+    the BVH scene and the out-of-step form the entry point's own loop over the shards."""
+    import ctypes as C
+    from gpu_util import DeviceBuffer, make_frame, sync, upload_scene
+    lib = pt.load_library()
+    V, T, M = {"default": scenes.default_scene, "materials": scenes.all_materials_scene, "synthetic700": lambda: scenes.synthetic_scene(700)}[scene_name]()
+    w, h, depth = 97, 41, 12
+    n, pitch = w * h, w * h + 37
+    scene_dev = upload_scene(pt, lib, pt.make_scene(V, T, M))
+    fr = make_frame(pt, oracle, w, h, depth=depth, rng_mode=1, stride=2 + 33 * depth, flags=scene_dev.frame_flags | (pt.PT_FRAME_OUT_OF_STEP if flags == "oos" else 0))
+    firsts = (C.c_uint32 * shards)(*[5 + 1000 * k for k in range(shards)])
+    out = []
+    for one_call in (False, True):
+        rng = DeviceBuffer(lib, n * 4)
+        assert lib.pt_hip_rng_seed(C.byref(fr), rng.ptr, None) == 0, lib.pt_hip_last_error()
+        mean = DeviceBuffer(lib, shards * pitch * 16).upload(np.ones(shards * pitch * 4, dtype=np.float32))
+        stats = DeviceBuffer(lib, pt.PT_STATS_WORDS * 8).upload(np.zeros(pt.PT_STATS_WORDS, dtype=np.uint64))
+        for mean_first, samples in ((0, 3), (3, 2)):
+            for k in range(shards):
+                firsts[k] = 5 + 1000 * k + mean_first
+            if one_call:
+                assert lib.pt_hip_render_fused_shards(C.byref(fr), scene_dev.ptr, len(T), len(M), firsts, shards, mean_first, samples,
+                                                      rng.ptr, mean.ptr, pitch, stats.ptr, None) == 0, lib.pt_hip_last_error()
+            else:
+                for k in range(shards):
+                    assert lib.pt_hip_render_fused(C.byref(fr), scene_dev.ptr, len(T), len(M), firsts[k], mean_first, samples,
+                                                   rng.ptr, mean.ptr + k * pitch * 16, stats.ptr, None) == 0, lib.pt_hip_last_error()
+        sync(lib)
+        out.append((mean.download(np.uint32).reshape(shards, pitch, 4)[:, :n], stats.download(np.uint64)[:8]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert not np.array_equal(out[0][0][0], out[0][0][1])                       # the shards did render different samples
+    # limits
+    assert lib.pt_hip_render_fused_shards(C.byref(fr), scene_dev.ptr, len(T), len(M), firsts, 17, 0, 1, rng.ptr, mean.ptr, pitch, None, None) == -5      # PT_ERR_LIMIT
+    assert lib.pt_hip_render_fused_shards(C.byref(fr), scene_dev.ptr, len(T), len(M), firsts, 2, 0, 1, rng.ptr, mean.ptr, n - 1, None, None) == -1      # PT_ERR_INVALID
