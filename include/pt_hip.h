@@ -66,8 +66,8 @@ enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
  * process-wide threshold, so a blob packed under one threshold stays valid after pt_hip_set_bvh_threshold changes it. */
 #define PT_FRAME_SCENE_BVH 2u
 /* Scenes of MORE triangles than this are packed with a BVH unless pt_hip_set_bvh_threshold says otherwise.  Measured on
- * MI355X at 1080p (tools/bvh_crossover.py, profiles/r02_bvh_crossover.txt): the 48-triangle all-materials scene runs 2x faster
- * looped over from LDS, at 108 triangles the BVH leads by 5 .. 22 % (level in one case of six), at 192 2x, at 432 4x .. 7x. */
+ * MI355X at 1080p (tools/bvh_crossover.py, profiles/r02_bvh_crossover.txt): the 48-triangle all-materials scene runs 1.5 .. 1.8x
+ * faster looped over from LDS when samples are batched, at 108 triangles the BVH leads 1.4 .. 2.5x, at 192 2 .. 4x. */
 #define PT_BVH_DEFAULT_MIN_TRIANGLES 96u
 /* PT_FRAME_OUT_OF_STEP (pt_hip_render_fused, scenes without a BVH): the 64 pixels of a wave take their samples out of step --
  * a lane whose path has ended starts its pixel's next sample while its neighbours still bounce -- instead of bounce by bounce

@@ -97,12 +97,17 @@ constexpr uint32_t kMaxClasses = 8;                // == ptd::kBvhMaxClasses
 constexpr double kClassAngle = 0.14;               // radians (8 degrees): how far a normal may be from its class's axis
 
 struct NormalClass { float axis[3], sin_h; };      // 16 bytes, what the traversal reads: axis * cos(h) (rounded down), sin(h) (rounded up)
-struct ClassBlock {                                // 192 bytes at the end of the BVH part of the blob
+// The displacement du e0 + dv e1 lies IN the triangle's plane: along a coordinate axis a it is at most |delta| sin(angle(normal, a)),
+// so a box need not grow along its triangles' normal at all.  Per class and axis: in_plane[a] = sin(min(90 deg, angle(class
+// axis, a) + h)) (rounded up) -- the walls of an axis-aligned room inflate within their own plane only, and a ray that
+// grazes them (the one with the large delta) is pruned by the slab across it.
+struct ClassBlock {                                // 320 bytes at the end of the BVH part of the blob
 	uint32_t n_classes, all_classified, _pad[2];
 	NormalClass cls[kMaxClasses];
+	float in_plane[kMaxClasses][4];                // {x, y, z, 0}
 	uint32_t _pad2[12];
 };
-static_assert(sizeof(ClassBlock) == 192, "class block is 192 bytes");
+static_assert(sizeof(ClassBlock) == 320, "class block is 320 bytes");
 
 struct Built {
 	ClassBlock classes{};
@@ -151,6 +156,11 @@ inline ClassBlock classify_normals(const std::vector<double>& n, const std::vect
 		// absolute on sin(h) keep the computed rho_k below the true |dhat . axis| cos(h) - sin(h)
 		for (int c = 0; c < 3; c++) out.cls[k].axis[c] = (float)(axes[k][c] / alen * std::cos(h) * (1.0 - 1e-4));
 		out.cls[k].sin_h = (float)(std::sin(h) * 1.0001 + 1e-5);
+		for (int c = 0; c < 3; c++) {
+			double to_axis = std::acos(std::min(1.0, std::fabs(axes[k][c]) / alen)) + h;          // a member's normal is at most this far from coordinate axis c ...
+			out.in_plane[k][c] = (float)std::min(1.0, (to_axis >= 1.5707963267948966 ? 1.0 : std::sin(to_axis)) * 1.0001 + 1e-6);   // ... or exactly across it
+		}
+		out.in_plane[k][3] = 0.0f;
 	}
 	return out;
 }

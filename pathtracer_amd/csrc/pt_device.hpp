@@ -199,14 +199,14 @@ __host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
 }
 
 constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block
-constexpr uint32_t kBvhClassBytes = 192;    // pt_bvh.hpp ClassBlock
+constexpr uint32_t kBvhClassBytes = 320;    // pt_bvh.hpp ClassBlock
 constexpr uint32_t kBvhMaxClasses = 8;      // == ptbvh::kMaxClasses
 constexpr float kBvhKappaRho = 16.0f * 5.9604645e-8f / 0.25f;     // == ptbvh::kKappaRho: inflation per unit of S, times the ray's rho (pt_bvh.hpp, normal classes)
 constexpr float kBvhRhoMin = 1e-4f;                              // == ptbvh::kRhoMin
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
-constexpr uint32_t kSceneMagic = 0x50544855u;  // "PTHU" (T: half nodes {box, child}; U: normal classes as {axis cos h, sin h}; older blobs are refused)
+constexpr uint32_t kSceneMagic = 0x50544856u;  // "PTHV" (T: half nodes {box, child}; U: normal classes as {axis cos h, sin h}; V: + in-plane factors; older blobs are refused)
 
 // The 16-bit grid the BVH's boxes are stored on (pt_bvh.hpp QNode): a cube around the scene's bounding sphere,
 // x = lo + q * cell, q = 0..65535.  Host (scene_pack) and device evaluate this same function.
@@ -315,6 +315,7 @@ struct BvhView {
 	bool det_bounded;        // SceneHeader::flags bit 0
 	int stack_depth;         // bvh_stack_depth(n_tris)
 	const float4* classes;   // pt_bvh.hpp NormalClass {axis * cos(h), sin(h)} x n_classes (wave-uniform reads)
+	const float4* in_plane;  // ... and per class how much of an in-plane displacement can point along x, y, z
 	uint32_t n_classes;      // 0: every ray keeps the worst-case inflation (slivers, or more plane directions than classes)
 	uint32_t n_nodes, n_tris; // sizes of `nodes` and `leaves`
 };
@@ -345,6 +346,7 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	const uint32_t* cb = reinterpret_cast<const uint32_t*>(scene + off + (size_t)n_tris * (kBvhNodeBytes + 64u));
 	v.n_classes = cb[1] != 0u ? (cb[0] < kBvhMaxClasses ? cb[0] : kBvhMaxClasses) : 0u;      // {n_classes, all_classified, ..}
 	v.classes = reinterpret_cast<const float4*>(cb + 4);
+	v.in_plane = v.classes + kBvhMaxClasses;
 	return v;
 }
 
@@ -484,37 +486,47 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	float delta_max = bv.kappa_root * bv.s_bound + bv.slack;
 	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
 	float delta_root = bv.kappa_root * s_ray + bv.slack;     // how far outside its triangle an accepted hit can be
-	// How close to grazing does this ray come to ANY triangle of the scene?  rho = min over the normal classes of
-	// |dhat . axis| cos(h) - sin(h) <= |cos(ray, normal)| (pt_bvh.hpp; the stored axis and sin(h) carry the margins for the
-	// ~1e-6 of dhat's v_rcp).  The boxes are inflated by kBvhKappaRho / rho * S -- size-independent, and graded: the closer to
-	// grazing, the wider -- never by more than the worst case, which is also what a ray below kBvhRhoMin gets.
-	float rho = bv.n_classes != 0u ? 1.0f : 0.0f;
-	{
-		float il = __builtin_amdgcn_rcpf(dlen);
-		Vec3 dh{ dd.x * il, dd.y * il, dd.z * il };
+	// How close to grazing does this ray come to the triangles of each normal class?  rho_k = |dhat . axis_k| cos(h_k) - sin(h_k)
+	// <= |cos(ray, normal)| for every triangle of class k (pt_bvh.hpp; the stored axis and sin(h) carry the margins for the ~1e-6
+	// of dhat's v_rcp).  An accepted hit on such a triangle has its true plane point within delta_k = kBvhKappaRho / rho_k * S of
+	// the triangle -- size-independent and graded: the closer to grazing, the wider, never more than the worst case, which is
+	// also what a class below kBvhRhoMin gets -- and that displacement lies IN the triangle's plane: along x, y, z it is at most
+	// delta_k * in_plane_k.  So the boxes grow per axis by the largest of those over the classes (a wall is not inflated across
+	// itself, which is exactly the slab that prunes the ray grazing it), and the ray interval by the largest delta_k.
+	Vec3 grow{ delta_root, delta_root, delta_root };
+	float delta_t = delta_root;
+	if (bv.n_classes != 0u) {
+		const float il_ = __builtin_amdgcn_rcpf(dlen);
+		Vec3 dh{ dd.x * il_, dd.y * il_, dd.z * il_ };
+		grow = Vec3{ 0.0f, 0.0f, 0.0f };
+		delta_t = 0.0f;
 		for (uint32_t k = 0; k < bv.n_classes; k++) {
-			float4 c = bv.classes[k];
-			rho = fminf(rho, fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) - c.w);
+			float4 c = bv.classes[k], ip = bv.in_plane[k];
+			float rho = fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) - c.w;
+			float dk = delta_root;
+			if (rho >= kBvhRhoMin) dk = fminf(delta_root, 1.0001f * kBvhKappaRho * __builtin_amdgcn_rcpf(rho) * s_ray + bv.slack);
+			grow.x = fmaxf(grow.x, dk * ip.x); grow.y = fmaxf(grow.y, dk * ip.y); grow.z = fmaxf(grow.z, dk * ip.z);
+			delta_t = fmaxf(delta_t, dk);
 		}
+		grow.x += bv.slack; grow.y += bv.slack; grow.z += bv.slack;       // (the box arithmetic's own slack is no in-plane quantity)
 	}
-	float delta_box = delta_root;
-	if (rho >= kBvhRhoMin) delta_box = fminf(delta_root, 1.0001f * kBvhKappaRho * __builtin_amdgcn_rcpf(rho) * s_ray + bv.slack);
-	// the same bound holds for the hit distance (t = f * (e1 . q) carries the same 1 / det): |t_true - t| |d| <= delta_box,
+	// the same bound holds for the hit distance (t = f * (e1 . q) carries the same 1 / det): |t_true - t| |d| <= delta_t,
 	// so the ray interval is widened to [-dt, best_t + dt] with it
-	r.dt = 1.01f * delta_box / dlen;
+	r.dt = 1.01f * delta_t / dlen;
 	// The origin in grid units.  Its own rounding (a subtraction, a product with the rounded 1/cell: under 4 ulp of a
 	// value that can reach 65535 + the camera's distance) and that of the slab's (q - o) go into the inflation, four
 	// times over: 1e-6 of the magnitudes involved -- hundredths of a cell, against boxes tens of cells wide.
 	Vec3 og{ (o.x - bv.glo.x) * bv.inv_cell, (o.y - bv.glo.y) * bv.inv_cell, (o.z - bv.glo.z) * bv.inv_cell };
 	// (+ 2 cells: the 2^23 bias of box_hit's decoded coordinates, see there)
-	float infl = 1.00001f * (delta_box * bv.inv_cell) + 1e-6f * (65536.0f + fabsf(og.x) + fabsf(og.y) + fabsf(og.z)) + 2.0f;
+	const float fixed = 1e-6f * (65536.0f + fabsf(og.x) + fabsf(og.y) + fabsf(og.z)) + 2.0f;
+	const float infl_x = 1.00001f * (grow.x * bv.inv_cell) + fixed, infl_y = 1.00001f * (grow.y * bv.inv_cell) + fixed, infl_z = 1.00001f * (grow.z * bv.inv_cell) + fixed;
 	// a ray with a positive direction component enters through lo - infl and leaves through hi + infl; a negative one the
 	// other way round.  c = -(2^23 + plane offset) * inv, the 2^23 apart so that the origin keeps its fraction of a cell.
 	const float bias = 8388608.0f;
 	bool px = dd.x >= 0.0f, py = dd.y >= 0.0f, pz = dd.z >= 0.0f;
 	r.snx = px ? kPermLo : kPermHi; r.sny = py ? kPermLo : kPermHi; r.snz = pz ? kPermLo : kPermHi;
 	// entry plane p = (positive ? lo - infl : hi + infl): t = (p - og) * inv = q * inv - (og + e) * inv, e = +/-infl; exit: - e
-	float ex = px ? infl : -infl, ey = py ? infl : -infl, ez = pz ? infl : -infl;
+	float ex = px ? infl_x : -infl_x, ey = py ? infl_y : -infl_y, ez = pz ? infl_z : -infl_z;
 	r.cn = Vec3{ -(og.x + ex) * r.inv.x - bias * r.inv.x, -(og.y + ey) * r.inv.y - bias * r.inv.y, -(og.z + ez) * r.inv.z - bias * r.inv.z };
 	r.cf = Vec3{ -(og.x - ex) * r.inv.x - bias * r.inv.x, -(og.y - ey) * r.inv.y - bias * r.inv.y, -(og.z - ez) * r.inv.z - bias * r.inv.z };
 	return r;

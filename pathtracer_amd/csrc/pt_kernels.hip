@@ -882,7 +882,7 @@ int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_tria
 
 size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
 	size_t n = bvh_offset_of(n_triangles, n_materials);
-	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B, the normal classes
+	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B, the normal classes (kBvhClassBytes)
 	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes;
 	return n;
 }

@@ -142,10 +142,10 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     while k > 2:
         k, balanced = (k + 1) // 2, balanced + 1
     # the blob: header, triangles, materials | nodes | leaf records | normal classes
-    assert n == bvh_off + (32 + 64) * n_tris + 192
+    assert n == bvh_off + (32 + 64) * n_tris + 320
     # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis * cos(h), sin(h)}: every triangle's plane lies in one of the
     # cones (half-angle h around the axis), so |dhat . axis| cos(h) - sin(h) bounds |cos(ray, normal)| from below
-    cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 192]
+    cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 320]
     n_classes, all_classified = int(cb[:8].view(np.uint32)[0]), int(cb[:8].view(np.uint32)[1])
     cls = cb[16:16 + 16 * 8].view(np.float32).reshape(8, 4).astype(np.float64)
     assert all_classified == 1 and n_classes == 3                # the faces of an axis-aligned box: three plane directions

@@ -195,7 +195,7 @@ def test_rho_of_the_normal_classes_bounds_the_cosine_to_every_triangle(pt, tilt,
     raw = np.frombuffer(pack(pt, V, T, M), dtype=np.uint8)
     hdr = raw[:64].view(np.uint32)
     n_tris, leaf_off = int(hdr[0]), int(hdr[8])
-    cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 192]
+    cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 320]
     n_classes, all_classified = (int(x) for x in cb[:8].view(np.uint32))
     assert all_classified == 1 and 3 <= n_classes <= 8
     cls = cb[16:16 + 16 * n_classes].view(np.float32).reshape(n_classes, 4).astype(np.float64)
@@ -213,6 +213,19 @@ def test_rho_of_the_normal_classes_bounds_the_cosine_to_every_triangle(pt, tilt,
     rho = (np.abs(d @ cls[:, :3].T) - cls[:, 3]).min(axis=1)
     cos_min = np.abs(d @ nrm.T).min(axis=1)
     assert (rho <= cos_min + 1e-12).all(), float((rho - cos_min).max())
+    # ... and the in-plane factors: a displacement within a member triangle's plane points along x, y, z by no more than in_plane[k]
+    in_plane = cb[16 + 16 * 8:16 + 16 * 8 + 16 * n_classes].view(np.float32).reshape(n_classes, 4).astype(np.float64)
+    # (for SOME class whose cone -- half-angle from the stored |axis cos h| and sin h -- holds the triangle's normal: the builder's
+    # greedy choice where cones overlap is not recorded, and any such class carries both bounds for the triangle)
+    unit_axes = cls[:, :3] / np.linalg.norm(cls[:, :3], axis=1, keepdims=True)
+    half_angle = np.arcsin(np.minimum(1.0, cls[:, 3]))
+    in_cone = np.arccos(np.minimum(1.0, np.abs(nrm @ unit_axes.T))) <= half_angle[None, :]
+    across = np.sqrt(np.maximum(0.0, 1.0 - nrm ** 2))                # per triangle and coordinate axis: sin(angle(normal, axis))
+    fits = (across[:, None, :] <= in_plane[None, :, :3] + 1e-12).all(axis=2)
+    assert (in_cone & fits).any(axis=1).all() and (in_plane[:, :3] <= 1.0).all()
+    assert (fits | ~in_cone).all()                                   # every cone that holds a normal bounds it
+    if tilt == 0.0:
+        assert np.sort(in_plane[:, :3], axis=1)[:, 0].max() < 3e-3     # a wall of an axis-aligned room is not inflated across itself
     # the bound is not vacuous: most random directions get a usable rho, and untilted rooms lose next to nothing
     assert (rho[:3000] >= 0.02).mean() > (0.85 if tilt == 0.0 else 0.3)
     if tilt == 0.0:
