@@ -102,9 +102,11 @@ struct NormalClass { float axis[3], sin_h; };      // 16 bytes, what the travers
 // axis, a) + h)) (rounded up) -- the walls of an axis-aligned room inflate within their own plane only, and a ray that
 // grazes them (the one with the large delta) is pruned by the slab across it.
 struct ClassBlock {                                // 320 bytes at the end of the BVH part of the blob
-	uint32_t n_classes, all_classified, _pad[2];
+	uint32_t n_classes, all_classified;
+	float kappa_free;                              // largest worst-case kappa among the triangles of no class (0: none)
+	uint32_t _pad;
 	NormalClass cls[kMaxClasses];
-	float in_plane[kMaxClasses][4];                // {x, y, z, 0}
+	float in_plane[kMaxClasses][4];                // {x, y, z, the class's largest worst-case kappa}
 	uint32_t _pad2[12];
 };
 static_assert(sizeof(ClassBlock) == 320, "class block is 320 bytes");
@@ -121,31 +123,47 @@ struct Built {
 
 struct Prim { float lo[3], hi[3], c[3]; float kappa; uint32_t idx; };
 
-// Greedy classification of the triangles' unit normals n (double, sign-agnostic); sliver[i]: never classified.
-inline ClassBlock classify_normals(const std::vector<double>& n, const std::vector<char>& sliver) {
+// Greedy classification of the triangles' unit normals n (double, sign-agnostic), LARGEST kappa first; sliver[i]: never
+// classified.  A triangle that finds no class (a sliver, or a ninth plane direction) is "free": it keeps its own worst-case
+// kappa, and the largest of those, kappa_free, is what every box is inflated by for them -- so a room of large quads with a
+// finely tessellated object in it gets classes for the quads (whose worst case would be larger than the room) and a small
+// kappa_free for the object, instead of the worst case of the largest triangle for every ray as long as one triangle
+// stayed unclassified.
+inline ClassBlock classify_normals(const std::vector<double>& n, const std::vector<char>& sliver, const std::vector<float>& kappa) {
 	ClassBlock out{};
 	const size_t count = sliver.size();
 	double axes[kMaxClasses][3];
 	double cos_h[kMaxClasses];
+	float kappa_of[kMaxClasses];                   // the largest worst-case kappa among a class's members: what a ray that grazes the class falls back to
 	uint32_t k_used = 0;
 	bool all = true;
+	float kappa_free = 0.0f;
 	const double cos_accept = std::cos(kClassAngle);
-	for (size_t i = 0; i < count; i++) {
-		if (sliver[i]) { all = false; continue; }
+	std::vector<uint32_t> order(count);
+	std::iota(order.begin(), order.end(), 0u);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return kappa[a] > kappa[b]; });
+	for (size_t oi = 0; oi < count; oi++) {
+		const size_t i = order[oi];
+		if (sliver[i] || !(kappa[i] == kappa[i])) { all = false; kappa_free = std::max(kappa_free, kappa[i] == kappa[i] ? kappa[i] : INFINITY); continue; }
 		const double* ni = &n[3 * i];
 		bool placed = false;
 		for (uint32_t k = 0; k < k_used && !placed; k++) {
 			double c = std::fabs(ni[0] * axes[k][0] + ni[1] * axes[k][1] + ni[2] * axes[k][2]);
-			if (c >= cos_accept) { cos_h[k] = std::min(cos_h[k], c); placed = true; }
+			// (a much smaller triangle joins only where it does not widen the cone: a wall's class must not come to graze every ray
+			// within kClassAngle of the wall for the sake of a facet that is cheap to leave free)
+			if (c >= cos_accept && (kappa[i] >= 0.25f * kappa_of[k] || c >= cos_h[k])) { cos_h[k] = std::min(cos_h[k], c); kappa_of[k] = std::max(kappa_of[k], kappa[i]); placed = true; }
 		}
 		if (!placed) {
-			if (k_used == kMaxClasses) { all = false; continue; }
+			// a new class only for triangles worth one: those of the size of the largest (the rest stay free, which costs their own small kappa)
+			if (k_used == kMaxClasses || (k_used != 0 && kappa[i] < 0.25f * kappa_of[0])) { all = false; kappa_free = std::max(kappa_free, kappa[i]); continue; }
 			for (int c = 0; c < 3; c++) axes[k_used][c] = ni[c];
 			cos_h[k_used] = 1.0;
+			kappa_of[k_used] = kappa[i];
 			k_used++;
 		}
 	}
-	// (a triangle that found no class leaves `all` false: its plane is covered by nothing, so no ray may be called calm)
+	out.kappa_free = kappa_free;
+	// (all_classified: no free triangle -- kept for readers of the blob; the traversal looks at kappa_free)
 	out.n_classes = k_used;
 	out.all_classified = (all && count > 0) ? 1u : 0u;
 	for (uint32_t k = 0; k < k_used; k++) {
@@ -160,7 +178,7 @@ inline ClassBlock classify_normals(const std::vector<double>& n, const std::vect
 			double to_axis = std::acos(std::min(1.0, std::fabs(axes[k][c]) / alen)) + h;          // a member's normal is at most this far from coordinate axis c ...
 			out.in_plane[k][c] = (float)std::min(1.0, (to_axis >= 1.5707963267948966 ? 1.0 : std::sin(to_axis)) * 1.0001 + 1e-6);   // ... or exactly across it
 		}
-		out.in_plane[k][3] = 0.0f;
+		out.in_plane[k][3] = kappa_of[k];
 	}
 	return out;
 }
@@ -386,7 +404,11 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, ui
 			normals[3 * (size_t)i + 0] = nl > 0.0 ? nx / nl : 0.0; normals[3 * (size_t)i + 1] = nl > 0.0 ? ny / nl : 0.0; normals[3 * (size_t)i + 2] = nl > 0.0 ? nz / nl : 0.0;
 		}
 	}
-	out.classes = classify_normals(normals, sliver);
+	{
+		std::vector<float> kappas(n_tris);
+		for (uint32_t i = 0; i < n_tris; i++) kappas[i] = prims[i].kappa;
+		out.classes = classify_normals(normals, sliver, kappas);
+	}
 	float r2 = 0.0f;
 	for (int k = 0; k < 3; k++) {
 		out.center[k] = n_tris ? 0.5f * (slo[k] + shi[k]) : 0.0f;

@@ -316,7 +316,8 @@ struct BvhView {
 	int stack_depth;         // bvh_stack_depth(n_tris)
 	const float4* classes;   // pt_bvh.hpp NormalClass {axis * cos(h), sin(h)} x n_classes (wave-uniform reads)
 	const float4* in_plane;  // ... and per class how much of an in-plane displacement can point along x, y, z
-	uint32_t n_classes;      // 0: every ray keeps the worst-case inflation (slivers, or more plane directions than classes)
+	uint32_t n_classes;      // 0: every ray keeps the worst-case inflation (kappa_free == kappa_root then)
+	float kappa_free;        // largest worst-case kappa among the triangles of no class: an isotropic inflation for them
 	uint32_t n_nodes, n_tris; // sizes of `nodes` and `leaves`
 };
 
@@ -344,7 +345,9 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	v.n_nodes = hdr->n_nodes;
 	v.n_tris = n_tris;
 	const uint32_t* cb = reinterpret_cast<const uint32_t*>(scene + off + (size_t)n_tris * (kBvhNodeBytes + 64u));
-	v.n_classes = cb[1] != 0u ? (cb[0] < kBvhMaxClasses ? cb[0] : kBvhMaxClasses) : 0u;      // {n_classes, all_classified, ..}
+	v.n_classes = cb[0] < kBvhMaxClasses ? cb[0] : kBvhMaxClasses;      // {n_classes, all_classified, kappa_free, ..}
+	v.kappa_free = v.n_classes != 0u ? fminf(__uint_as_float(cb[2]), hdr->kappa_root) : hdr->kappa_root;      // (inf / NaN from a degenerate triangle: the worst case)
+	if (!(v.kappa_free == v.kappa_free)) v.kappa_free = hdr->kappa_root;
 	v.classes = reinterpret_cast<const float4*>(cb + 4);
 	v.in_plane = v.classes + kBvhMaxClasses;
 	return v;
@@ -489,8 +492,8 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	// How close to grazing does this ray come to the triangles of each normal class?  rho_k = |dhat . axis_k| cos(h_k) - sin(h_k)
 	// <= |cos(ray, normal)| for every triangle of class k (pt_bvh.hpp; the stored axis and sin(h) carry the margins for the ~1e-6
 	// of dhat's v_rcp).  An accepted hit on such a triangle has its true plane point within delta_k = kBvhKappaRho / rho_k * S of
-	// the triangle -- size-independent and graded: the closer to grazing, the wider, never more than the worst case, which is
-	// also what a class below kBvhRhoMin gets -- and that displacement lies IN the triangle's plane: along x, y, z it is at most
+	// the triangle -- size-independent and graded: the closer to grazing, the wider, never more than the class's own worst case
+	// (that of its largest triangle), which is also what a class below kBvhRhoMin gets -- and that displacement lies IN the triangle's plane: along x, y, z it is at most
 	// delta_k * in_plane_k.  So the boxes grow per axis by the largest of those over the classes (a wall is not inflated across
 	// itself, which is exactly the slab that prunes the ray grazing it), and the ray interval by the largest delta_k.
 	Vec3 grow{ delta_root, delta_root, delta_root };
@@ -498,13 +501,15 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	if (bv.n_classes != 0u) {
 		const float il_ = __builtin_amdgcn_rcpf(dlen);
 		Vec3 dh{ dd.x * il_, dd.y * il_, dd.z * il_ };
-		grow = Vec3{ 0.0f, 0.0f, 0.0f };
-		delta_t = 0.0f;
+		// the triangles of no class (slivers, a ninth plane direction): their own worst case, in every direction
+		const float delta_free = bv.kappa_free > 0.0f ? bv.kappa_free * s_ray : 0.0f;
+		grow = Vec3{ delta_free, delta_free, delta_free };
+		delta_t = delta_free + bv.slack;
 		for (uint32_t k = 0; k < bv.n_classes; k++) {
 			float4 c = bv.classes[k], ip = bv.in_plane[k];
 			float rho = fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) - c.w;
-			float dk = delta_root;
-			if (rho >= kBvhRhoMin) dk = fminf(delta_root, 1.0001f * kBvhKappaRho * __builtin_amdgcn_rcpf(rho) * s_ray + bv.slack);
+			float dk = fminf(delta_root, ip.w * s_ray + bv.slack);      // the class's own worst case (its largest triangle's)
+			if (rho >= kBvhRhoMin) dk = fminf(dk, 1.0001f * kBvhKappaRho * __builtin_amdgcn_rcpf(rho) * s_ray + bv.slack);
 			grow.x = fmaxf(grow.x, dk * ip.x); grow.y = fmaxf(grow.y, dk * ip.y); grow.z = fmaxf(grow.z, dk * ip.z);
 			delta_t = fmaxf(delta_t, dk);
 		}

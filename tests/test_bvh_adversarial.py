@@ -97,6 +97,29 @@ def tilted_room(n_tris, seed, tilt, rotate=True):
     return [_f32(p) for p in P], [(a, b, c, m % 3) for (a, b, c, m) in T], MATS
 
 
+def room_with_a_ball(n_room, n_ball, seed, tilt=0.0):
+    """the room of large quads with a finely tessellated ball in it: the classes go to the largest triangles (the walls, three
+    plane directions), every facet is a triangle of NO class and keeps its own small worst case (ClassBlock::kappa_free) -- the
+    mixed scene the classes exist for"""
+    rng = np.random.default_rng(seed)
+    V, T, M = tilted_room(n_room, seed, tilt, rotate=False)
+    rings, segs = max(3, int(round((n_ball / 2) ** 0.5))), max(4, int(round((n_ball / 2) ** 0.5)) * 2)
+    c, rad = np.array([0.15, -0.1, 0.6]) + rng.uniform(-0.05, 0.05, 3), 0.35
+    base = len(V)
+    for i in range(rings + 1):
+        th = np.pi * i / rings
+        for j in range(segs):
+            ph = 2 * np.pi * j / segs
+            V.append(_f32(c + rad * np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])))
+    for i in range(rings):
+        for j in range(segs):
+            a, b = base + i * segs + j, base + i * segs + (j + 1) % segs
+            d, e = a + segs, b + segs
+            if i > 0: T.append((a, d, b, int(rng.integers(0, 3))))           # (outward facing: the camera sits outside the ball)
+            if i < rings - 1: T.append((b, d, e, int(rng.integers(0, 3))))
+    return V, T, M
+
+
 def grazing_rays(V, T, n_rays, seed):
     """rays aimed at points on and just off the edges of chosen triangles, almost in their planes, from inside the scene's ball"""
     rng = np.random.default_rng(seed)
@@ -142,7 +165,9 @@ CASES = [("slivers", lambda: sliver_scene(900, 1)), ("slivers far from the origi
          ("four decades of sizes", lambda: scales_scene(1500, 3)), ("four decades, far from the origin", lambda: scales_scene(900, 4, offset=(-64.0, 200.0, 31.0))),
          ("coplanar sheets", lambda: sheets_scene(12)), ("coplanar sheets far from the origin", lambda: sheets_scene(10, offset=(1000.0, 1000.0, -1000.0))),
          ("room of large quads", lambda: tilted_room(300, 5, 0.0, rotate=False)), ("rotated room of large tilted quads", lambda: tilted_room(432, 6, 0.05)),
-         ("rotated room, quads tilted to the edge of their class", lambda: tilted_room(300, 7, 0.12))]
+         ("rotated room, quads tilted to the edge of their class", lambda: tilted_room(300, 7, 0.12)),
+         ("room of large quads with a tessellated ball", lambda: room_with_a_ball(300, 1200, 8)),
+         ("tilted room with a coarse ball", lambda: room_with_a_ball(192, 200, 9, tilt=0.04))]
 
 
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
@@ -230,3 +255,26 @@ def test_rho_of_the_normal_classes_bounds_the_cosine_to_every_triangle(pt, tilt,
     assert (rho[:3000] >= 0.02).mean() > (0.85 if tilt == 0.0 else 0.3)
     if tilt == 0.0:
         assert (cos_min[:3000] - rho[:3000]).max() < 2e-3
+
+
+def test_free_triangles_keep_their_own_worst_case(pt):
+    """ClassBlock::kappa_free: the ball's facets have no class (classes go to the largest triangles first -- the walls -- and a much
+    smaller triangle neither opens one nor widens one), their own worst-case kappa is recorded and is far below the scene's
+    largest (the walls', which the classes take care of)"""
+    import struct
+    V, T, M = room_with_a_ball(300, 1200, 8)
+    raw = np.frombuffer(pack(pt, V, T, M), dtype=np.uint8)
+    hdr = raw[:64].view(np.uint32)
+    n_tris, leaf_off = int(hdr[0]), int(hdr[8])
+    cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 320]
+    n_classes, all_classified = (int(x) for x in cb[:8].view(np.uint32))
+    kappa_free = float(cb[8:12].view(np.float32)[0])
+    kappa_root = struct.unpack_from("<f", raw.tobytes(), 52)[0]
+    assert n_classes == 3 and all_classified == 0                    # the walls' three plane directions; no facet is worth a class or may widen one
+    P = np.array([v[:3] for v in V], dtype=np.float64)
+    tri = np.array([t[:3] for t in T])
+    e0, e1 = P[tri[:, 1]] - P[tri[:, 0]], P[tri[:, 2]] - P[tri[:, 0]]
+    kappa = 24.0 * 2.0 ** -24 / 1e-6 * np.linalg.norm(e0, axis=1) * np.linalg.norm(e1, axis=1)
+    assert abs(kappa_root - kappa.max()) < 1e-3 * kappa.max()
+    ball = kappa[300:]
+    assert 0.0 < kappa_free <= ball.max() * 1.001 and kappa_free < 0.05 * kappa_root

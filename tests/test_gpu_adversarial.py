@@ -23,3 +23,20 @@ def test_edges_on_pixel_boundaries(pt, oracle, name, engine, w, h, seed):
     diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
     assert not diff.any(), f"{name}: {int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
     assert np.array_equal(rng, ref_rng) and got.rays == st.rays
+
+
+@pytest.mark.parametrize("name,engine", [("fused", 1), ("wavefront", 0)])
+def test_room_with_a_tessellated_ball(pt, oracle, name, engine):
+    """classes for the walls, free triangles (ClassBlock::kappa_free) for the ball's facets: every pixel against the oracle"""
+    from test_bvh_adversarial import room_with_a_ball
+    V, T, M = room_with_a_ball(300, 1200, 8)
+    w, h, spp, depth = 96, 64, 3, 8
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        tr.set_options(engine=engine, depth=depth)
+        tr.render(spp)
+        img, rng, got = tr.readback(), tr.readback_rng(), tr.stats()
+    diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+    assert not diff.any(), f"{name}: {int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+    assert np.array_equal(rng, ref_rng) and got.rays == st.rays
