@@ -86,6 +86,45 @@ int device_cus() {
 	return n;
 }
 
+// ---- scene guard.  Whether a blob is traversed with its BVH is the CALLER's word (PT_FRAME_SCENE_BVH in pt_frame.flags): the launchers
+// cannot look into device memory.  So every kernel that walks the BVH or loops over all triangles compares that word with the
+// blob's own header (one wave-uniform load) before it touches anything else: a BVH kernel on a blob packed without one would walk
+// nodes past the end of the blob, and the loop over 10^4..10^5 triangles of a blob that has one is a forgotten flag, not a wish.
+// On a mismatch the block returns at once and leaves a code in ONE pinned host word (a vector store over the bus; kernel completion
+// makes it visible), which every synchronising entry point looks at afterwards: the call that would have handed out the results
+// returns PT_ERR_STATE instead.
+__device__ uint32_t* g_guard_word;               // per device: where this process's guard word is mapped (null until guard_ready)
+uint32_t* guard_host_word() {
+	static uint32_t* word = [] {
+		void* p = nullptr;
+		if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return (uint32_t*)nullptr;
+		std::memset(p, 0, 64);
+		return (uint32_t*)p;
+	}();
+	return word;
+}
+// once per device, before the first guarded launch there (the calling thread's current device)
+void guard_ready() {
+	constexpr int kMaxDevices = 64;
+	static std::atomic<int> done[kMaxDevices];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || done[dev].load(std::memory_order_acquire)) return;
+	uint32_t* host = guard_host_word();
+	void* mapped = nullptr;
+	if (!host || hipHostGetDevicePointer(&mapped, host, 0) != hipSuccess) return;          // no word: the kernels still refuse, silently
+	uint32_t* m = (uint32_t*)mapped;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(g_guard_word), &m, sizeof(m)) == hipSuccess) done[dev].store(1, std::memory_order_release);
+}
+// after a synchronisation: has a kernel refused its scene since the last look?
+int guard_check() {
+	volatile uint32_t* w = guard_host_word();
+	if (!w || *w == 0u) return PT_OK;
+	const uint32_t code = *w;
+	*w = 0u;
+	return fail(PT_ERR_STATE, code == 1u ? "a kernel refused its scene: PT_FRAME_SCENE_BVH is set in pt_frame.flags but the blob carries no BVH (or is not the blob of these counts); its output is undefined"
+	                                      : "a kernel refused its scene: the blob carries a BVH (pt_hip_scene_has_bvh) but PT_FRAME_SCENE_BVH is not set in pt_frame.flags; its output is undefined");
+}
+
 int grid_for(size_t work_items) {
 	size_t blocks = (work_items + kBlock - 1) / kBlock;
 	size_t cap = (size_t)device_cus() * 8;          // 8 blocks of 256 per CU = 32 waves per CU
@@ -151,6 +190,16 @@ using JumpMat = JumpMats<1>;
 // SceneHeader::flags bit 0 (wave-uniform scalar load): pt_device.hpp, ray_triangle
 __device__ __forceinline__ bool scene_det_bounded(const unsigned char* scene) {
 	return scene && (reinterpret_cast<const SceneHeader*>(scene)->flags & kSceneDetBounded) != 0;
+}
+// the scene guard's device side (see guard_ready): block-uniform, so a block that returns on it does so as a whole
+__device__ __forceinline__ bool scene_guard(const unsigned char* scene, uint32_t n_tris, bool want_bvh) {
+	const SceneHeader* h = reinterpret_cast<const SceneHeader*>(scene);
+	const bool ok = h->magic == kSceneMagic && h->n_tris == n_tris && (h->n_nodes != 0u) == want_bvh;
+	if (!ok && threadIdx.x == 0u) {
+		uint32_t* w = g_guard_word;
+		if (w) *w = want_bvh ? 1u : 2u;
+	}
+	return ok;
 }
 struct SceneInfo { uint32_t n_tris, n_mats; bool bvh; };        // bvh: PT_FRAME_SCENE_BVH of the frame the blob came with
 
@@ -232,6 +281,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 came
                                                    const uint32_t* __restrict__ count_ptr, uint32_t capacity,
                                                    uint2* __restrict__ hit) {
 	extern __shared__ float4 s_tris[];
+	if (!scene_guard(scene, n_tris, BVH)) return;
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const uint32_t G = gridDim.x;
 	const uint32_t count = count_ptr[blockIdx.x];
@@ -277,7 +327,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 came
 
 template <bool FIRST, bool SCENE_LDS, bool EXTEND>
 __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
-                                                  uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
+                                                  uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce, uint32_t scene_bvh,
                                                   const float4* __restrict__ qa, const float4* __restrict__ qb,
                                                   const float4* __restrict__ qc, const uint32_t* __restrict__ qpid,
                                                   const uint2* __restrict__ hit,
@@ -291,6 +341,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 	static_assert(!EXTEND || SCENE_LDS, "the fused extend intersects against the LDS copy of the scene");
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
+	// (shade itself reads no BVH, but the hits it is handed come from an extend stage that refuses on this same word: stay in step with it)
+	if (!scene_guard(scene, n_tris, scene_bvh != 0u)) return;
 	stage_jump31(s_jump);
 	const bool det_bounded = scene_det_bounded(scene);
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
@@ -331,6 +383,7 @@ __global__ __launch_bounds__(kBlock, PT_TAIL_WAVES) void k_bounce_tail(FrameDev 
 	uint32_t* s_stack = reinterpret_cast<uint32_t*>(s_dyn);
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_next, s_count[PT_MAX_DEPTH + 1];
+	if (!scene_guard(scene, n_tris, true)) return;
 	stage_jump31(s_jump);
 	if (threadIdx.x == 0) s_next = 0;
 	if (threadIdx.x <= PT_MAX_DEPTH) s_count[threadIdx.x] = 0;
@@ -358,6 +411,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_stride[1024];       // STRIDED: byte tables of step^stride
 	__shared__ uint32_t s_out, s_traced, s_round[2];
+	if (!scene_guard(scene, n_tris, false)) return;
 	stage_jump31(s_jump);
 	const bool strided = !SEQ;
 	// STRIDED: step^(frame_first*stride), the start of the pass's first sample, and step^stride, from sample to sample
@@ -465,6 +519,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 	__shared__ uint32_t s_first[STRIDED ? 32 * MAXS : 1], s_per_sample[STRIDED ? 32 : 1];
 	// ... and step^stride, taken once per sample whose draws differ from the stride, as a byte table (4 lookups instead of 32 columns)
 	__shared__ uint32_t s_stride[STRIDED ? 1024 : 1];
+	if (!scene_guard(scene, n_tris, BVH)) return;
 	if (STRIDED) {
 		for (uint32_t t = threadIdx.x; t < 32u * ns; t += kBlock) s_first[t] = first.cols[t];
 		if (threadIdx.x < 32) s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x];
@@ -616,6 +671,7 @@ __global__ __launch_bounds__(kBlock, PT_FUSED_BVH_WAVES) void k_fused_bvh(FrameD
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per_sample[STRIDED ? 32 : 1], s_stride[STRIDED ? 1024 : 1];
 	__shared__ uint32_t s_next;
+	if (!scene_guard(scene, n_tris, true)) return;
 	if (STRIDED && threadIdx.x < 32) { s_first[threadIdx.x] = first.cols[threadIdx.x]; s_per_sample[threadIdx.x] = per_sample.cols[threadIdx.x]; }
 	if (STRIDED) { __syncthreads(); build_stride_table(s_per_sample, s_stride); }
 	if (threadIdx.x == 0) s_next = 0;
@@ -752,6 +808,7 @@ void launch_extend(const FrameDev& f, uint32_t bounce, const void* scene_blob, c
 	dim3 grid(grid_for(capacity)), block(kBlock);
 	const unsigned char* sc = (const unsigned char*)scene_blob;
 	bool bvh = scene_has_bvh(si);
+	guard_ready();
 	size_t lds = bvh ? (size_t)bvh_stack_depth(si.n_tris) * kBlock * sizeof(uint32_t) : extend_lds_bytes(si.n_tris);
 #define PT_EXT(FIRST, BVH) hipLaunchKernelGGL((k_extend<FIRST, BVH>), grid, block, lds, s, f.origin, f.origin, sc, si.n_tris, si.n_mats, qa, qb, counts, capacity, hit)
 	if (bounce == 0) { if (bvh) PT_EXT(true, true); else PT_EXT(true, false); }
@@ -816,7 +873,7 @@ int pt_hip_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream) {
 	if (!d || !h) return fail(PT_ERR_INVALID, "memcpy_d2h: null pointer");
 	HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
 	HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-	return PT_OK;
+	return guard_check();
 }
 int pt_hip_memcpy_d2d(void* d, const void* src, size_t bytes, void* stream) {
 	if (bytes == 0) return PT_OK;
@@ -852,7 +909,7 @@ int pt_hip_stream_create(void** stream) {
 	return PT_OK;
 }
 int pt_hip_stream_destroy(void* stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return PT_OK; }
-int pt_hip_stream_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return PT_OK; }
+int pt_hip_stream_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return guard_check(); }
 int pt_hip_event_create(void** event) {
 	if (!event) return fail(PT_ERR_INVALID, "event is null");
 	hipEvent_t e;
@@ -875,7 +932,7 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
 	if (!start || !stop || !ms) return fail(PT_ERR_INVALID, "event_elapsed_ms: null pointer");
 	HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
 	HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
-	return PT_OK;
+	return guard_check();
 }
 
 int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_triangles; return PT_OK; }
@@ -1058,7 +1115,8 @@ static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneIn
 	if (extend && !lds) return fail(PT_ERR_INVALID, "shade: the fused extend needs a scene that fits LDS (<= 1536 triangles, <= 256 materials)");
 	size_t lds_bytes = shade_lds_bytes(si);
 	dim3 grid(grid_for(capacity)), block(kBlock);
-#define PT_SHADE(FIRST, LDS, EXT) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, \
+	guard_ready();
+#define PT_SHADE(FIRST, LDS, EXT) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, si.bvh ? 1u : 0u, \
 	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
 	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng)
 	if (bounce == 0) { if (extend) PT_SHADE(true, true, true); else if (lds) PT_SHADE(true, true, false); else PT_SHADE(true, false, false); }
@@ -1126,6 +1184,7 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 	hipStream_t s = (hipStream_t)stream;
 	SceneInfo si = scene_info(frame, n_triangles, n_materials);
 	FrameDev f = to_dev(*frame);
+	guard_ready();
 	const bool sequential = frame->rng_mode == PT_RNG_SEQUENTIAL;
 	// scene resident in LDS: the whole pass is one launch (k_bounces)
 	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si) && bounces_lds_bytes(si) <= kBouncesLdsBudget;
@@ -1265,6 +1324,7 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	hipStream_t s = (hipStream_t)stream;
 	SceneInfo si = scene_info(frame, n_triangles, n_materials);
 	FrameDev f = to_dev(*frame);
+	guard_ready();
 	JumpMat first{}, per{};
 	bool strided = frame->rng_mode == PT_RNG_STRIDED;
 	if (strided) {
@@ -1335,6 +1395,7 @@ int pt_hip_render_fused_shards(const pt_frame* frame, const void* scene_blob, ui
 	}
 	hipStream_t s = (hipStream_t)stream;
 	FrameDev f = to_dev(*frame);
+	guard_ready();
 	JumpMats<PT_FUSED_MAX_SHARDS> first{};
 	JumpMat per{};
 	for (uint32_t k = 0; k < n_shards; k++) host_jump_matrix((uint64_t)frame_first[k] * frame->stride, first.cols + 32u * k);
