@@ -266,8 +266,9 @@ public:
 
 	const pt_options& Options() const { return _opt; }
 
-	int SetOptions(const pt_options& in) {
-		if (_error) return _error;
+	// What SetOptions accepts, checked without touching the instance (LoadState validates a file's options with it before
+	// anything of the live accumulation is given up).
+	int _ValidateOptions(const pt_options& in) const {
 		if (in.engine != PT_ENGINE_WAVEFRONT && in.engine != PT_ENGINE_FUSED && in.engine != PT_ENGINE_AUTO) return plugin_fail(PT_ERR_INVALID, "unknown engine");
 		if (in.rng_mode != PT_RNG_SEQUENTIAL && in.rng_mode != PT_RNG_STRIDED) return plugin_fail(PT_ERR_INVALID, "unknown rng_mode");
 		if (in.depth < 1 || in.depth > PT_MAX_DEPTH) return plugin_fail(PT_ERR_INVALID, "depth must be 1..32");
@@ -291,6 +292,12 @@ public:
 			if (v % ranks) return plugin_fail(PT_ERR_INVALID, "split_ranks must divide virtual_shards");
 		}
 		if (in.device != _opt.device && in.device >= 0) return plugin_fail(PT_ERR_STATE, "device is chosen before Create (pt_set_default_device / pt_create_on_device)");
+		return PT_OK;
+	}
+
+	int SetOptions(const pt_options& in) {
+		if (_error) return _error;
+		if (int rc = _ValidateOptions(in)) return rc;
 		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		bool realloc = in.pixel_first != _opt.pixel_first || in.pixel_count != _opt.pixel_count ||
@@ -478,17 +485,23 @@ public:
 			return plugin_fail(PT_ERR_INVALID, "load_state: not a state file of this library version");
 		if ((int)hd.width != _width || (int)hd.height != _height) return plugin_fail(PT_ERR_STATE, "load_state: the state was saved at " + std::to_string(hd.width) + "x" + std::to_string(hd.height) + " (Resize first)");
 		if (hd.scene_hash != _sceneHash || hd.n_tris != _nTris || hd.n_mats != _nMats) return plugin_fail(PT_ERR_STATE, "load_state: the state was saved on another scene (pt_set_scene first)");
-		DeviceScope bind(_device);
+		// Everything that can be wrong with the file is found BEFORE the instance is touched: SetOptions reallocates, reseeds and
+		// zeroes the counters, so a refusal after it would already have cost the live accumulation.
 		pt_options o = hd.options;
 		o.device = _opt.device;                      // the device is this instance's, whatever the saving one ran on
-		if (int rc = SetOptions(o)) return rc;       // validates, sizes the buffers, restarts
-		if (hd.pixel_first != _pixelFirst || hd.pixel_count != _pixelCount || hd.local_shards != _localShards || hd.pitch != _pitch)
+		if (int rc = _ValidateOptions(o)) return rc;
+		Layout l{};
+		if (!_LayoutOf(o, _width, _height, &l) || hd.pixel_first != l.pixel_first || hd.pixel_count != l.pixel_count || hd.local_shards != l.local_shards || hd.pitch != l.pitch)
 			return plugin_fail(PT_ERR_INVALID, "load_state: the file's layout does not follow from its options");
-		std::vector<uint32_t> rng(_pixelCount);
-		std::vector<float> mean((size_t)_pitch * _localShards * 4);
+		std::vector<uint32_t> rng(l.pixel_count);
+		std::vector<float> mean((size_t)l.pitch * l.local_shards * 4);
 		if (std::fread(rng.data(), sizeof(uint32_t), rng.size(), f) != rng.size() || std::fread(mean.data(), sizeof(float), mean.size(), f) != mean.size() ||
 		    std::fgetc(f) != EOF)
 			return plugin_fail(PT_ERR_INVALID, "load_state: the file is truncated or has trailing bytes");
+		DeviceScope bind(_device);
+		if (int rc = SetOptions(o)) return rc;       // sizes the buffers, restarts
+		if (l.pixel_first != _pixelFirst || l.pixel_count != _pixelCount || l.local_shards != _localShards || l.pitch != _pitch)
+			return plugin_fail(PT_ERR_INVALID, "load_state: internal: SetOptions and _LayoutOf disagree");
 		PT_TRY(pt_hip_memcpy_h2d(_dev.rng, rng.data(), rng.size() * sizeof(uint32_t), _stream));
 		PT_TRY(pt_hip_memcpy_h2d(_dev.mean, mean.data(), mean.size() * sizeof(float), _stream));
 		PT_TRY(pt_hip_memcpy_h2d(_dev.stats, hd.stats, sizeof(hd.stats), _stream));
@@ -587,28 +600,43 @@ private:
 		return PT_OK;
 	}
 
+	// Which pixels, how many shard means and how far apart: what an instance of this size holds under these options.  A pure
+	// function of its arguments, so that a state file can be checked against it before the instance is touched.
+	struct Layout { uint32_t ranks, pixel_first, pixel_count, v_shards, local_shards, slice, pitch; };
+	static bool _LayoutOf(const pt_options& o, int width, int height, Layout* out) {
+		const uint64_t n = (uint64_t)width * (uint64_t)height;
+		Layout l{};
+		l.ranks = o.split_mode == PT_SPLIT_NONE ? 1u : std::max(o.split_ranks, 1u);
+		if (o.split_mode == PT_SPLIT_TILE) {
+			if (l.ranks > n || o.split_rank >= l.ranks) return false;
+			l.pixel_first = (uint32_t)(n * o.split_rank / l.ranks);
+			l.pixel_count = (uint32_t)(n * (o.split_rank + 1) / l.ranks) - l.pixel_first;
+		} else {
+			const bool fits = o.pixel_first < n && (uint64_t)o.pixel_first + o.pixel_count <= n;
+			l.pixel_first = fits ? o.pixel_first : 0u;
+			l.pixel_count = fits && o.pixel_count ? o.pixel_count : (uint32_t)(n - l.pixel_first);
+		}
+		if (o.split_mode == PT_SPLIT_SAMPLE) {
+			l.v_shards = o.virtual_shards ? o.virtual_shards : PT_VIRTUAL_SHARDS;
+			l.local_shards = l.v_shards / l.ranks;
+			l.slice = (l.pixel_count + l.ranks - 1) / l.ranks;
+			l.pitch = l.slice * l.ranks;
+		} else {
+			l.v_shards = 1; l.local_shards = 1; l.slice = l.pixel_count; l.pitch = l.pixel_count;
+		}
+		*out = l;
+		return true;
+	}
+
 	// PathTracer.cu:217-233
 	int _AllocateDrawingMemory() {
 		uint64_t n = (uint64_t)_width * _height;
 		if (n > 0x7FFFFFFFull) return plugin_fail(PT_ERR_LIMIT, "image larger than 2^31-1 pixels");
-		_ranks = _opt.split_mode == PT_SPLIT_NONE ? 1u : std::max(_opt.split_ranks, 1u);
-		if (_opt.split_mode == PT_SPLIT_TILE) {
-			if (_ranks > n || _opt.split_rank >= _ranks) return plugin_fail(PT_ERR_INVALID, "tile split does not fit the image");
-			_pixelFirst = (uint32_t)(n * _opt.split_rank / _ranks);
-			_pixelCount = (uint32_t)(n * (_opt.split_rank + 1) / _ranks) - _pixelFirst;
-		} else {
-			if (_opt.pixel_first >= n || (uint64_t)_opt.pixel_first + _opt.pixel_count > n) { _opt.pixel_first = 0; _opt.pixel_count = 0; }
-			_pixelFirst = _opt.pixel_first;
-			_pixelCount = _opt.pixel_count ? _opt.pixel_count : (uint32_t)(n - _pixelFirst);
-		}
-		if (SampleSplit()) {
-			_vShards = _opt.virtual_shards ? _opt.virtual_shards : PT_VIRTUAL_SHARDS;
-			_localShards = _vShards / _ranks;
-			_slice = (_pixelCount + _ranks - 1) / _ranks;
-			_pitch = _slice * _ranks;
-		} else {
-			_vShards = 1; _localShards = 1; _slice = _pixelCount; _pitch = _pixelCount;
-		}
+		if (_opt.split_mode != PT_SPLIT_TILE && (_opt.pixel_first >= n || (uint64_t)_opt.pixel_first + _opt.pixel_count > n)) { _opt.pixel_first = 0; _opt.pixel_count = 0; }
+		Layout l{};
+		if (!_LayoutOf(_opt, _width, _height, &l)) return plugin_fail(PT_ERR_INVALID, "tile split does not fit the image");
+		_ranks = l.ranks; _pixelFirst = l.pixel_first; _pixelCount = l.pixel_count;
+		_vShards = l.v_shards; _localShards = l.local_shards; _slice = l.slice; _pitch = l.pitch;
 		_imageCurrent = false;
 		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked);
 		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _dev.image = nullptr; _dev.stacked = nullptr;

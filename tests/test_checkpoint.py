@@ -112,6 +112,39 @@ def test_damaged_state_files_are_refused(pt, tmp_path):
         assert tr.stats().frames == 2
 
 
+def test_refused_file_leaves_the_live_accumulation_alone(pt, tmp_path):
+    """a file that is refused for its BODY (truncated, trailing bytes, a layout that does not follow from its options)
+    is found out before the instance is touched: frames, mean, streams, counters and options stay, and rendering goes on from
+    them bit for bit."""
+    good = str(tmp_path / "other.bin")
+    with pt.PathTracer(40, 24) as other:              # a state with OTHER options than the instance that will refuse its damaged copies
+        other.set_options(engine=0, depth=4, rng_mode=1, stride=2 + 33 * 4, samples_per_pass=2)
+        other.render(2)
+        other.save_state(good)
+    data = open(good, "rb").read()
+    with pt.PathTracer(40, 24) as ref:
+        ref.set_options(engine=1, depth=7)
+        ref.render(3)
+        ref.render(2)
+        want = _snapshot(ref)
+    with pt.PathTracer(40, 24) as tr:
+        tr.set_options(engine=1, depth=7)
+        tr.render(3)
+        before = _snapshot(tr)
+        opts_before = (tr.get_options().engine, tr.get_options().depth, tr.get_options().rng_mode, tr.get_options().samples_per_pass)
+        for name, blob in (("truncated", data[:-5]), ("trailing", data + b"x"), ("header-only", data[:len(data) - 40 * 24 * 20])):
+            bad = str(tmp_path / name)
+            open(bad, "wb").write(blob)
+            with pytest.raises(pt.PathTracerError, match="truncated or has trailing"):
+                tr.load_state(bad)
+            after = _snapshot(tr)
+            assert np.array_equal(bits(after[0]), bits(before[0])) and np.array_equal(after[1], before[1]) and after[2] == before[2], name
+            assert (tr.get_options().engine, tr.get_options().depth, tr.get_options().rng_mode, tr.get_options().samples_per_pass) == opts_before, name
+        tr.render(2)                                  # and the accumulation goes on as if nothing had been tried
+        got = _snapshot(tr)
+    assert np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+
+
 def test_pending_camera_change_cannot_be_saved(pt, tmp_path):
     with pt.PathTracer(32, 16) as tr:
         tr.render(1)
