@@ -94,16 +94,20 @@ def scene_of(name):
     raise ValueError(name)
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, script=None):
     """--gpus N without a launcher: start the N ranks as a torch.distributed.run child.  Nothing in THIS process has
-    touched the GPU (no torch.cuda, no plugin call), and it replaces nothing: it waits and exits with the child's code."""
+    touched the GPU (no torch.cuda, no plugin call -- torch is not even imported yet), and it replaces nothing: it waits and
+    exits with the child's code.  `script`: what the ranks run (this file; tests/test_bench_launch.py passes a stub)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
+    # RCCL shares device buffers between the ranks' processes through IPC handles, and this pool's host driver only supports
+    # the dmabuf kind: with the legacy mode the first collective fails with `hipIpcGetMemHandle: invalid argument`.  The image
+    # exports the variable already; it is set here too so that a cleaned environment (a test runner, a service unit) still works.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+           "--master-port", str(port), os.path.abspath(script or __file__)] + argv
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -224,6 +228,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the sample split and its RCCL exchange even with one rank (self-test of the N>1 path)")
     ap.add_argument("--exchange", choices=["torch", "native"], default="torch", help="N>1: torch.distributed collectives (RCCL) or the plugin's own pt_dist_combine (RCCL)")
     ap.add_argument("--exchange-every", type=int, default=0, help="N>1: exchange after every E-th step, beside the next render; 0 = once, after the last step (inside the timed region)")
+    ap.add_argument("--dump-image", default=None, help="N>1 path: rank 0 writes the combined image (float32 [pixels, 4], .npy) here after the timed region (tests)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     args = ap.parse_args()
@@ -290,6 +295,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "tolerance.json")) as f:
                     out["tolerance"] = json.load(f)       # tools/fma_tolerance.py: the oracle built with FMA contraction against the strict one
+                out["tolerance"]["measured_in_this_run"] = False          # a committed file (profiles/tolerance.json), read, not measured here
             except Exception:
                 pass
             # outside the timed region: a sustained loop of the same step, the other engine, the other configs
@@ -400,6 +406,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    t_rendered = time.perf_counter() - t0                         # FinalizeDrawing has waited for this rank's last step
     if not args.exchange_every or args.steps % args.exchange_every:
         exchange()                                                # the render's one reduce (configs[2]'s shape)
     sync()
@@ -407,11 +414,14 @@ def main():
     st = tracer.stats()
     rays_rank = st.rays - st0.rays
     kernel_ms = (st.total_render_ms - st0.total_render_ms) / max(1, st.renders - st0.renders)
-    t = torch.tensor([dt, float(rays_rank)], device="cuda", dtype=torch.float64)
+    # per-phase figures for whoever reads a SCALE run: this rank's render wall time, and what came after it (the exchange, then
+    # the wait for the slowest rank at the barrier) -- the MAX over ranks of each, and the MIN of the render time beside it
+    t = torch.tensor([dt, float(rays_rank), t_rendered, dt - t_rendered, -t_rendered], device="cuda", dtype=torch.float64)
     tmax = t.clone()
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     dt, rays_total = float(tmax[0]), float(t[1])
+    render_ms_max, exchange_ms, render_ms_min = float(tmax[2]) * 1e3, float(tmax[3]) * 1e3, -float(tmax[4]) * 1e3
     # every rank holds the same image: a checksum of checksums over the ranks
     img = tracer.readback() if native else image[:n_pix * 4].cpu().numpy().reshape(n_pix, 4)
     digest = int(np.bitwise_xor.reduce(img.view(np.uint32).reshape(-1)))
@@ -433,8 +443,13 @@ def main():
                                       f"{exchanges} exchange(s) in the timed region ({'pt_dist_combine' if native else 'torch.distributed'} over RCCL: all_to_all of slices, fixed-order tree, all_gather)"},
             "rccl_ranks": rccl_ranks, "exchanges_timed": exchanges, "image_identical_on_all_ranks": same_image,
             "kernel_ms_per_step": round(kernel_ms, 4),
+            "render_ms_max": round(render_ms_max, 4), "render_ms_min": round(render_ms_min, 4), "exchange_ms": round(exchange_ms, 4),
+            "phases": "render_ms_max / render_ms_min: wall time of a rank's timed steps (max / min over ranks); exchange_ms: the rest of the timed "
+                      "region on the rank where it was longest (the exchange, then the barrier's wait for the slowest rank)",
             "roofline": roof, "cpu_baseline": None,
         }
+        if args.dump_image:
+            np.save(args.dump_image, np.ascontiguousarray(img[:n_pix]))
         emit(out)
     tracer.Destroy()
     dist.barrier()

@@ -104,10 +104,13 @@ struct NormalClass { float axis[3], sin_h; };      // 16 bytes, what the travers
 struct ClassBlock {                                // 320 bytes at the end of the BVH part of the blob
 	uint32_t n_classes, all_classified;
 	float kappa_free;                              // largest worst-case kappa among the triangles of no class (0: none)
-	uint32_t _pad;
+	uint32_t free_root;                            // node index of the FREE triangles' own tree (0: one tree only), see build()
 	NormalClass cls[kMaxClasses];
 	float in_plane[kMaxClasses][4];                // {x, y, z, the class's largest worst-case kappa}
-	uint32_t _pad2[12];
+	uint32_t first_is_free;                        // 1: the tree at node 0 holds the free triangles (no triangle has a class)
+	uint32_t n_classified;                         // leaf records [0, n_classified) are the classified triangles, the rest the free ones
+	float free_max_edge;                           // longest edge among the free triangles
+	uint32_t _pad2[9];
 };
 static_assert(sizeof(ClassBlock) == 320, "class block is 320 bytes");
 
@@ -129,9 +132,11 @@ struct Prim { float lo[3], hi[3], c[3]; float kappa; uint32_t idx; };
 // finely tessellated object in it gets classes for the quads (whose worst case would be larger than the room) and a small
 // kappa_free for the object, instead of the worst case of the largest triangle for every ray as long as one triangle
 // stayed unclassified.
-inline ClassBlock classify_normals(const std::vector<double>& n, const std::vector<char>& sliver, const std::vector<float>& kappa) {
+inline ClassBlock classify_normals(const std::vector<double>& n, const std::vector<char>& sliver, const std::vector<float>& kappa,
+                                   std::vector<int>* class_of = nullptr) {
 	ClassBlock out{};
 	const size_t count = sliver.size();
+	if (class_of) class_of->assign(count, -1);         // -1: free
 	double axes[kMaxClasses][3];
 	double cos_h[kMaxClasses];
 	float kappa_of[kMaxClasses];                   // the largest worst-case kappa among a class's members: what a ray that grazes the class falls back to
@@ -151,7 +156,10 @@ inline ClassBlock classify_normals(const std::vector<double>& n, const std::vect
 			double c = std::fabs(ni[0] * axes[k][0] + ni[1] * axes[k][1] + ni[2] * axes[k][2]);
 			// (a much smaller triangle joins only where it does not widen the cone: a wall's class must not come to graze every ray
 			// within kClassAngle of the wall for the sake of a facet that is cheap to leave free)
-			if (c >= cos_accept && (kappa[i] >= 0.25f * kappa_of[k] || c >= cos_h[k])) { cos_h[k] = std::min(cos_h[k], c); kappa_of[k] = std::max(kappa_of[k], kappa[i]); placed = true; }
+			if (c >= cos_accept && (kappa[i] >= 0.25f * kappa_of[k] || c >= cos_h[k])) {
+				cos_h[k] = std::min(cos_h[k], c); kappa_of[k] = std::max(kappa_of[k], kappa[i]); placed = true;
+				if (class_of) (*class_of)[i] = (int)k;
+			}
 		}
 		if (!placed) {
 			// a new class only for triangles worth one: those of the size of the largest (the rest stay free, which costs their own small kappa)
@@ -159,6 +167,7 @@ inline ClassBlock classify_normals(const std::vector<double>& n, const std::vect
 			for (int c = 0; c < 3; c++) axes[k_used][c] = ni[c];
 			cos_h[k_used] = 1.0;
 			kappa_of[k_used] = kappa[i];
+			if (class_of) (*class_of)[i] = (int)k_used;
 			k_used++;
 		}
 	}
@@ -352,10 +361,10 @@ inline int32_t build_range(std::vector<Prim>& p, uint32_t a, uint32_t b, uint32_
 }
 
 // inner levels on the longest root-to-leaf path = the most deferred siblings a traversal can hold
-inline uint32_t inner_depth(const std::vector<Node>& nodes) {
+inline uint32_t inner_depth(const std::vector<Node>& nodes, uint32_t root = 0) {
 	if (nodes.empty()) return 0;
 	uint32_t deepest = 0;
-	std::vector<std::pair<int32_t, uint32_t>> todo{ { 0, 1u } };
+	std::vector<std::pair<int32_t, uint32_t>> todo{ { (int32_t)root, 1u } };
 	while (!todo.empty()) {
 		auto [i, d] = todo.back();
 		todo.pop_back();
@@ -404,10 +413,11 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, ui
 			normals[3 * (size_t)i + 0] = nl > 0.0 ? nx / nl : 0.0; normals[3 * (size_t)i + 1] = nl > 0.0 ? ny / nl : 0.0; normals[3 * (size_t)i + 2] = nl > 0.0 ? nz / nl : 0.0;
 		}
 	}
+	std::vector<int> class_of;
 	{
 		std::vector<float> kappas(n_tris);
 		for (uint32_t i = 0; i < n_tris; i++) kappas[i] = prims[i].kappa;
-		out.classes = classify_normals(normals, sliver, kappas);
+		out.classes = classify_normals(normals, sliver, kappas, &class_of);
 	}
 	float r2 = 0.0f;
 	for (int k = 0; k < 3; k++) {
@@ -418,17 +428,48 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, ui
 	out.radius = std::sqrt(r2);
 	out.nodes.reserve(n_tris);
 	if (n_tris == 0) return out;
-	int32_t root = build_range(prims, 0, n_tris, stack_depth, out);
-	if (root < 0) {                                   // a single leaf: wrap it so the root is always node 0
-		Node n{};
-		bounds_of(prims, 0, n_tris, n.lo0, n.hi0, n.kappa0);
-		n.child0 = root;
-		for (int k = 0; k < 3; k++) { n.lo1[k] = 1e30f; n.hi1[k] = -1e30f; }  // inside-out box (65535..0 on the grid): (almost) never entered; entering it re-tests one triangle, which is harmless
-		n.child1 = encode_leaf(0, 1);
-		n.kappa1 = 0.0f;
-		out.nodes.push_back(n);
+	// ---- two trees.  What a ray owes a CLASSIFIED triangle (graded by how close it comes to grazing the class's planes: up to the
+	// class's own worst case, within the plane) and what it owes a FREE one (kappa_free, always, in every direction) are different
+	// inflations, and in one tree every box pays the larger: round 2's room of large quads with a 40 000-facet ball ran at 0.1 Grays/s
+	// because the few rays in 1000 that come within rho ~ 1e-3 of a wall inflated every box OF THE BALL by more than a facet's size.
+	// So the classified triangles get a tree of their own (node 0) and the free ones another (ClassBlock::free_root); a ray walks
+	// the first with the class inflation alone, then the second with kappa_free alone (pt_device.hpp: a marker on the traversal
+	// stack switches the ray's constants between the two).  Hits are ranked by (t, original index) whatever the order of the
+	// tests, so the result is still the loop over all triangles.  The marker takes one stack level: with two trees each is built
+	// one level inside the budget.  A scene whose triangles are all classified, or all free, has one tree as before.
+	std::stable_partition(prims.begin(), prims.end(), [&](const Prim& q) { return class_of[q.idx] >= 0; });
+	uint32_t n_cls = 0;
+	for (uint32_t i = 0; i < n_tris; i++) {
+		if (class_of[i] >= 0) n_cls++;
+		else {
+			const pt_float4 &a = v[t[i].vertexIdx0].position, &b = v[t[i].vertexIdx1].position, &c = v[t[i].vertexIdx2].position;
+			auto len = [](const pt_float4& p, const pt_float4& q) { float x = q.x - p.x, y = q.y - p.y, z = q.z - p.z; return std::sqrt(x * x + y * y + z * z); };
+			out.classes.free_max_edge = std::max(out.classes.free_max_edge, std::max(len(a, b), std::max(len(a, c), len(b, c))));
+		}
 	}
-	out.kappa_root = std::max(out.nodes[0].kappa0, out.nodes[0].kappa1);
+	const bool two = n_cls != 0 && n_cls != n_tris;
+	const uint32_t budget = two ? stack_depth - 1u : stack_depth;
+	auto build_tree = [&](uint32_t a, uint32_t b) -> uint32_t {
+		const uint32_t root_at = (uint32_t)out.nodes.size();
+		int32_t root = build_range(prims, a, b, budget, out);
+		if (root < 0) {                                   // a single leaf: wrap it so that a tree's root is always a node
+			Node n{};
+			bounds_of(prims, a, b, n.lo0, n.hi0, n.kappa0);
+			n.child0 = root;
+			for (int k = 0; k < 3; k++) { n.lo1[k] = 1e30f; n.hi1[k] = -1e30f; }  // inside-out box (65535..0 on the grid): (almost) never entered; entering it re-tests one triangle, which is harmless
+			n.child1 = encode_leaf(a, 1);
+			n.kappa1 = 0.0f;
+			out.nodes.push_back(n);
+		}
+		return root_at;
+	};
+	if (two) {
+		build_tree(0, n_cls);
+		out.classes.free_root = build_tree(n_cls, n_tris);
+	} else build_tree(0, n_tris);
+	out.classes.first_is_free = n_cls == 0 ? 1u : 0u;
+	out.classes.n_classified = n_cls;
+	for (uint32_t i = 0; i < n_tris; i++) out.kappa_root = std::max(out.kappa_root, prims[i].kappa == prims[i].kappa ? prims[i].kappa : INFINITY);
 	out.tris.resize(n_tris);
 	for (uint32_t k = 0; k < n_tris; k++) {
 		uint32_t i = prims[k].idx;

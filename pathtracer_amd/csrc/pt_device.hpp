@@ -206,7 +206,7 @@ constexpr float kBvhRhoMin = 1e-4f;                              // == ptbvh::kR
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
-constexpr uint32_t kSceneMagic = 0x50544856u;  // "PTHV" (T: half nodes {box, child}; U: normal classes as {axis cos h, sin h}; V: + in-plane factors; older blobs are refused)
+constexpr uint32_t kSceneMagic = 0x50544857u;  // "PTHW" (T: half nodes {box, child}; U: normal classes as {axis cos h, sin h}; V: + in-plane factors; W: the free triangles in a tree of their own; older blobs are refused)
 
 // The 16-bit grid the BVH's boxes are stored on (pt_bvh.hpp QNode): a cube around the scene's bounding sphere,
 // x = lo + q * cell, q = 0..65535.  Host (scene_pack) and device evaluate this same function.
@@ -319,6 +319,8 @@ struct BvhView {
 	uint32_t n_classes;      // 0: every ray keeps the worst-case inflation (kappa_free == kappa_root then)
 	float kappa_free;        // largest worst-case kappa among the triangles of no class: an isotropic inflation for them
 	uint32_t n_nodes, n_tris; // sizes of `nodes` and `leaves`
+	uint32_t free_root;      // node index of the free triangles' own tree, walked after the tree at node 0 (0: one tree only)
+	bool first_free;         // the tree at node 0 holds the free triangles (no triangle of the scene has a class)
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -350,6 +352,8 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	if (!(v.kappa_free == v.kappa_free)) v.kappa_free = hdr->kappa_root;
 	v.classes = reinterpret_cast<const float4*>(cb + 4);
 	v.in_plane = v.classes + kBvhMaxClasses;
+	v.free_root = cb[3] < v.n_nodes ? cb[3] : 0u;
+	v.first_free = v.n_classes == 0u || cb[4 + 8 * kBvhMaxClasses] != 0u;       // ClassBlock::first_is_free
 	return v;
 }
 
@@ -459,6 +463,11 @@ __device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint
 // triangle per trip.  Leaves are never tested inline in the node step: measured on the 10k-triangle scene, the
 // inline form kept 8.5 of 64 lanes busy per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
 constexpr int32_t kBvhDone = 0x7FFFFFFF;
+// Scenes with two trees (pt_bvh.hpp build: classified triangles at node 0, free ones at BvhView::free_root): the traversal stack of a
+// fresh ray holds this marker below everything else; popping it means the first tree is done, and bvh_round then re-derives the
+// ray's box constants for the free tree (kappa_free alone) and goes on at its root.  A lane that holds it neither walks nor
+// stands on a leaf.
+constexpr int32_t kBvhSwitch = 0x7FFFFFFE;
 #ifndef PT_BVH_SPECULATE
 #define PT_BVH_SPECULATE 0     // measured: parking one leaf and walking on costs 25-30 % (10k triangles 2.77 -> 2.02 Grays/s): the parked leaf usually ends the search
 #endif
@@ -477,7 +486,10 @@ constexpr int kBvhQuorum = PT_BVH_QUORUM;
 #define PT_BVH_RATIO 4
 #endif
 
-__device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 d, float best_t) {
+// free_tree: the constants for the walk of the FREE triangles' tree (their worst case kappa_free, in every direction, and nothing
+// for the classes); otherwise for the classified triangles' tree (the classes' graded, in-plane inflation, and nothing for
+// kappa_free).  A scene with one tree holds either only classified or only free triangles (BvhView::first_free).
+__device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 d, float best_t, bool free_tree) {
 	// a zero component would make 0 * inf = NaN in the slabs; a direction error of 1e-20 is far inside the inflation
 	Vec3 dd{ fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x, fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y,
 	         fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z };
@@ -498,13 +510,17 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	// itself, which is exactly the slab that prunes the ray grazing it), and the ray interval by the largest delta_k.
 	Vec3 grow{ delta_root, delta_root, delta_root };
 	float delta_t = delta_root;
-	if (bv.n_classes != 0u) {
+	if (free_tree) {
+		// the triangles of no class (slivers, a ninth plane direction, the facets of a finely tessellated object among large
+		// walls): their own worst case, in every direction (kappa_free <= kappa_root: make_bvh_view)
+		const float delta_free = bv.kappa_free * s_ray + bv.slack;
+		grow = Vec3{ delta_free, delta_free, delta_free };
+		delta_t = delta_free;
+	} else if (bv.n_classes != 0u) {
 		const float il_ = __builtin_amdgcn_rcpf(dlen);
 		Vec3 dh{ dd.x * il_, dd.y * il_, dd.z * il_ };
-		// the triangles of no class (slivers, a ninth plane direction): their own worst case, in every direction
-		const float delta_free = bv.kappa_free > 0.0f ? bv.kappa_free * s_ray : 0.0f;
-		grow = Vec3{ delta_free, delta_free, delta_free };
-		delta_t = delta_free + bv.slack;
+		grow = Vec3{ 0.0f, 0.0f, 0.0f };
+		delta_t = bv.slack;
 		for (uint32_t k = 0; k < bv.n_classes; k++) {
 			float4 c = bv.classes[k], ip = bv.in_plane[k];
 			float rho = fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) - c.w;
@@ -545,12 +561,19 @@ __device__ __forceinline__ int32_t bvh_pop(uint32_t* stack, int& sp) {
 	return (int32_t)stack[sp * 256];
 }
 
+// A fresh ray: at the root of the tree at node 0, and -- scenes with two trees -- the marker that leads on to the second below
+// everything its walk will stack (the constants the ray starts with are bvh_ray_setup(.., bv.first_free)).
+__device__ __forceinline__ void bvh_start(const BvhView& bv, int32_t& cur, int& sp, uint32_t* stack) {
+	cur = 0; sp = 0;
+	if (bv.free_root != 0u) { stack[0] = (uint32_t)kBvhSwitch; sp = 1; }
+}
+
 // One round of the traversal: walk inner nodes until the lane stands on a leaf (or is done), then test that leaf's
 // triangles, every lane in lockstep.  With PT_BVH_SPECULATE a lane that reaches a leaf parks it in `pend` and keeps
 // walking until it holds a second leaf, so that fewer lanes idle while the slowest lane still looks for its first
 // one -- tried, and slower (see the define).  The order in which leaves are tested cannot
 // change the result: bvh_leaf ranks hits by (t, original index).
-__device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
+__device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
                                           int32_t& cur, int& sp, uint32_t* stack PT_TIME_PARAM) {
 	constexpr int32_t kNone = 0;                       // node 0 is the root and never a child, so 0 is free as "no parked leaf"
 	int32_t pend = kNone;
@@ -558,13 +581,13 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 	for (;;) {
 		if (kBvhQuorum > 0) {
 			// (every lane of the calling context reaches these ballots: lanes that stand on a leaf stay in the loop, idle)
-			unsigned long long walking = __ballot((uint32_t)cur < (uint32_t)kBvhDone);
+			unsigned long long walking = __ballot((uint32_t)cur < (uint32_t)kBvhSwitch);
 			if (walking == 0ull) break;
 			int leafy = __popcll(__ballot(cur < 0));
 			if (leafy > 0 && (__popcll(walking) < kBvhQuorum || (PT_BVH_RATIO > 0 && __popcll(walking) * PT_BVH_RATIO < leafy * 4))) break;
 		}
-		PT_COUNT_WAVE((uint32_t)cur < (uint32_t)kBvhDone, 0, 1);
-		if ((uint32_t)cur < (uint32_t)kBvhDone) {
+		PT_COUNT_WAVE((uint32_t)cur < (uint32_t)kBvhSwitch, 0, 1);
+		if ((uint32_t)cur < (uint32_t)kBvhSwitch) {
 			PT_CHECK((uint32_t)cur < bv.n_nodes && sp >= 0 && sp <= bv.stack_depth, { cur = kBvhDone; sp = 0; continue; });
 			const uint4* n = bv.nodes + (size_t)cur * 2;
 			uint4 w0 = n[0], w1 = n[1];
@@ -603,13 +626,20 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, const BvhRay& r, Ve
 		}
 		PT_TIME_END(5);
 	}
+	// the first tree is done (the marker came off the stack in the node walk or after the leaf): on to the free triangles' tree,
+	// with the constants that tree is walked with -- and with the hit distance the first tree has left, which is all the tighter
+	if (bv.free_root != 0u && cur == kBvhSwitch) {
+		r = bvh_ray_setup(bv, o, d, best_t, true);
+		cur = (int32_t)bv.free_root;
+	}
 }
 
 __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
                                               uint32_t* stack) {
-	BvhRay r = bvh_ray_setup(bv, o, d, best_t);
-	int32_t cur = 0;
-	int sp = 0;
+	BvhRay r = bvh_ray_setup(bv, o, d, best_t, bv.first_free);
+	int32_t cur;
+	int sp;
+	bvh_start(bv, cur, sp, stack);
 	PT_TIME_NULL();
 	while (cur != kBvhDone) bvh_round(bv, r, o, d, best_t, hit_tri, cur, sp, stack PT_TIME_ARG);
 }
@@ -664,11 +694,11 @@ __device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origi
 					d = FIRST ? Vec3{ b.x, b.y, b.z } : Vec3{ a.w, b.x, b.y };
 					best = FIRST ? FLT_MAX : b.z;
 					tri = kNoHit;
-					r = bvh_ray_setup(bv, o, d, best);
+					r = bvh_ray_setup(bv, o, d, best, bv.first_free);
 					// (from the root.  Starting at the leaf of the triangle the ray leaves -- the siblings along that leaf's root path
 					// box-tested and stacked, which spares half of a bounced ray's node steps -- was built and measured, DESIGN 4.4:
 					// -3..-4 % here and -4..-8 % in k_fused_bvh: the tests lengthen the refill, which stalls the lanes still walking)
-					cur = 0; sp = 0; has_ray = true;
+					bvh_start(bv, cur, sp, stack); has_ray = true;
 				}
 			}
 		}

@@ -169,8 +169,8 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 			if (fresh) {
 				n_rays++;
 				tri = kNoHit;
-				r = bvh_ray_setup(c.bv, o, d, best);
-				cur = 0; sp = 0;
+				r = bvh_ray_setup(c.bv, o, d, best, c.bv.first_free);
+				bvh_start(c.bv, cur, sp, stack);
 			}
 		}
 		if (!__any(cur != kBvhDone)) break;      // after a service nobody walks only if nobody had anything left to do

@@ -475,8 +475,8 @@ __device__ __forceinline__ void bounce_tail_block(const ShadeCtx& c, const BvhVi
 			if (fresh) {
 				best = r.t;
 				tri = kNoHit;
-				ray = bvh_ray_setup(bv, r.o, r.d, best);
-				cur = 0; sp = 0;
+				ray = bvh_ray_setup(bv, r.o, r.d, best, bv.first_free);
+				bvh_start(bv, cur, sp, stack);
 			}
 		}
 		if (!__any(cur != kBvhDone)) {            // a lane that holds a path walks: nobody walking = no path in flight
