@@ -319,8 +319,9 @@ struct BvhView {
 	uint32_t n_classes;      // 0: every ray keeps the worst-case inflation (kappa_free == kappa_root then)
 	float kappa_free;        // largest worst-case kappa among the triangles of no class: an isotropic inflation for them
 	uint32_t n_nodes, n_tris; // sizes of `nodes` and `leaves`
-	uint32_t free_root;      // node index of the free triangles' own tree, walked after the tree at node 0 (0: one tree only)
-	bool first_free;         // the tree at node 0 holds the free triangles (no triangle of the scene has a class)
+	uint32_t second_root;    // node index of the second tree's root, walked after the tree at node 0 (0: one tree only)
+	bool first_free;         // the tree at node 0 holds the free triangles (no triangle has a class); else a second tree, if any, does
+	const float* free_bounds; // ClassBlock {free_max_edge, free_center[3], free_radius}: bounds S for the free triangles per ray
 };
 
 __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uint32_t n_tris, uint32_t n_mats, float4 origin) {
@@ -352,7 +353,8 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	if (!(v.kappa_free == v.kappa_free)) v.kappa_free = hdr->kappa_root;
 	v.classes = reinterpret_cast<const float4*>(cb + 4);
 	v.in_plane = v.classes + kBvhMaxClasses;
-	v.free_root = cb[3] < v.n_nodes ? cb[3] : 0u;
+	v.second_root = cb[3] < v.n_nodes ? cb[3] : 0u;
+	v.free_bounds = reinterpret_cast<const float*>(cb + 4 + 8 * kBvhMaxClasses + 2);
 	v.first_free = v.n_classes == 0u || cb[4 + 8 * kBvhMaxClasses] != 0u;       // ClassBlock::first_is_free
 	return v;
 }
@@ -463,10 +465,10 @@ __device__ __forceinline__ void bvh_leaf(const float4* __restrict__ leaves, uint
 // triangle per trip.  Leaves are never tested inline in the node step: measured on the 10k-triangle scene, the
 // inline form kept 8.5 of 64 lanes busy per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
 constexpr int32_t kBvhDone = 0x7FFFFFFF;
-// Scenes with two trees (pt_bvh.hpp build: classified triangles at node 0, free ones at BvhView::free_root): the traversal stack of a
-// fresh ray holds this marker below everything else; popping it means the first tree is done, and bvh_round then re-derives the
-// ray's box constants for the free tree (kappa_free alone) and goes on at its root.  A lane that holds it neither walks nor
-// stands on a leaf.
+// Scenes with two trees (pt_bvh.hpp build: classified triangles at node 0, free ones at BvhView::second_root): the traversal stack
+// of a fresh ray holds this marker below everything else; popping it means the first tree is done, and bvh_round then re-derives
+// the ray's box constants for the second tree (kappa_free alone) and goes on at its root.  A lane that holds it neither
+// walks nor stands on a leaf.
 constexpr int32_t kBvhSwitch = 0x7FFFFFFE;
 #ifndef PT_BVH_SPECULATE
 #define PT_BVH_SPECULATE 0     // measured: parking one leaf and walking on costs 25-30 % (10k triangles 2.77 -> 2.02 Grays/s): the parked leaf usually ends the search
@@ -496,10 +498,13 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	BvhRay r;
 	r.inv = Vec3{ bv.cell / dd.x, bv.cell / dd.y, bv.cell / dd.z };
 	float dlen = __builtin_sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
-	// S for THIS ray: an accepted hit has computed t < best_t, so its vertex is no farther from the origin
-	// than best_t*|d| + edge (+ the error delta itself, bounded with the launch-wide S); never more than s_bound
+	// S for THIS ray (S >= |origin - v0| + 0.86 edge, pt_bvh.hpp): an accepted hit has computed t < best_t and its true plane point
+	// lies within delta of the triangle, every point of which is within an edge's length of v0 -- so |origin - v0| <= best_t |d| +
+	// edge + 2 delta (the error of t and the displacement, both bounded with the launch-wide S), and S <= best_t |d| + 2 edges +
+	// 2 delta; never more than s_bound.  (Rounds 1 and 2 had ONE edge here: short by up to 0.8 of an edge for hits nearer than
+	// sixteen edges -- inside the head-room of the constants on every scene tested, but the claim is a bound.)
 	float delta_max = bv.kappa_root * bv.s_bound + bv.slack;
-	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + bv.max_edge) + 2.0f * delta_max);
+	float s_ray = fminf(bv.s_bound, 1.05f * (best_t * dlen + 2.0f * bv.max_edge) + 2.0f * delta_max);
 	float delta_root = bv.kappa_root * s_ray + bv.slack;     // how far outside its triangle an accepted hit can be
 	// How close to grazing does this ray come to the triangles of each normal class?  rho_k = |dhat . axis_k| cos(h_k) - sin(h_k)
 	// <= |cos(ray, normal)| for every triangle of class k (pt_bvh.hpp; the stored axis and sin(h) carry the margins for the ~1e-6
@@ -512,8 +517,17 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	float delta_t = delta_root;
 	if (free_tree) {
 		// the triangles of no class (slivers, a ninth plane direction, the facets of a finely tessellated object among large
-		// walls): their own worst case, in every direction (kappa_free <= kappa_root: make_bvh_view)
-		const float delta_free = bv.kappa_free * s_ray + bv.slack;
+		// walls): their own worst case, in every direction (kappa_free <= kappa_root: make_bvh_view).  S for THEM: a vertex of a
+		// free triangle lies in the sphere around the free triangles, and an accepted hit's vertex within best_t |d| + a FREE
+		// triangle's edge (+ 2 delta) of the origin -- a ball of small facets in a large room owes kappa_free times its own
+		// distance, not the room's size (what s_bound and the scene's longest edge say)
+		const float e_free = bv.free_bounds[0], r_free = bv.free_bounds[4];
+		const float ox = o.x - bv.free_bounds[1], oy = o.y - bv.free_bounds[2], oz = o.z - bv.free_bounds[3];
+		const float s_sphere = 1.0001f * (__builtin_sqrtf(ox * ox + oy * oy + oz * oz) + r_free + e_free) + 1e-6f;
+		const float s_launch = fminf(bv.s_bound, s_sphere);                   // (NaN / inf from a degenerate triangle: fminf keeps s_bound)
+		const float dmax_free = bv.kappa_free * s_launch + bv.slack;
+		const float s_free = fminf(s_launch, 1.05f * (best_t * dlen + 2.0f * e_free) + 2.0f * dmax_free);
+		const float delta_free = bv.kappa_free * s_free + bv.slack;
 		grow = Vec3{ delta_free, delta_free, delta_free };
 		delta_t = delta_free;
 	} else if (bv.n_classes != 0u) {
@@ -565,7 +579,7 @@ __device__ __forceinline__ int32_t bvh_pop(uint32_t* stack, int& sp) {
 // everything its walk will stack (the constants the ray starts with are bvh_ray_setup(.., bv.first_free)).
 __device__ __forceinline__ void bvh_start(const BvhView& bv, int32_t& cur, int& sp, uint32_t* stack) {
 	cur = 0; sp = 0;
-	if (bv.free_root != 0u) { stack[0] = (uint32_t)kBvhSwitch; sp = 1; }
+	if (bv.second_root != 0u) { stack[0] = (uint32_t)kBvhSwitch; sp = 1; }
 }
 
 // One round of the traversal: walk inner nodes until the lane stands on a leaf (or is done), then test that leaf's
@@ -626,11 +640,11 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 		}
 		PT_TIME_END(5);
 	}
-	// the first tree is done (the marker came off the stack in the node walk or after the leaf): on to the free triangles' tree,
-	// with the constants that tree is walked with -- and with the hit distance the first tree has left, which is all the tighter
-	if (bv.free_root != 0u && cur == kBvhSwitch) {
+	// the first tree is done (the marker came off the stack in the node walk or after the leaf): on to the second, with the
+	// constants that tree is walked with -- and with the hit distance the first has left, which makes them all the tighter
+	if (bv.second_root != 0u && cur == kBvhSwitch) {
 		r = bvh_ray_setup(bv, o, d, best_t, true);
-		cur = (int32_t)bv.free_root;
+		cur = (int32_t)bv.second_root;
 	}
 }
 

@@ -984,8 +984,8 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles, bvh_stack_depth(n_triangles));
 			if (bvh.nodes.size() > n_triangles) return fail(PT_ERR_LIMIT, "scene_pack: BVH larger than its reservation");
 			// (two trees: the marker that leads from the first to the second takes one level of the stack under the first one's walk)
-			const uint32_t levels = bvh_stack_depth(n_triangles), marker = bvh.classes.free_root != 0u ? 1u : 0u;
-			if (ptbvh::inner_depth(bvh.nodes, 0) + marker > levels || (marker && ptbvh::inner_depth(bvh.nodes, bvh.classes.free_root) > levels))
+			const uint32_t levels = bvh_stack_depth(n_triangles), marker = bvh.classes.second_root != 0u ? 1u : 0u;
+			if (ptbvh::inner_depth(bvh.nodes, 0) + marker > levels || (marker && ptbvh::inner_depth(bvh.nodes, bvh.classes.second_root) > levels))
 				return fail(PT_ERR_LIMIT, "scene_pack: BVH deeper than the traversal stack");
 			hdr.n_nodes = (uint32_t)bvh.nodes.size();
 			float glo[3], cell;

@@ -282,7 +282,7 @@ def test_free_triangles_keep_their_own_worst_case(pt):
 
 def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
     """one inflation per ray charged what a ray owes the walls to every box of the ball.  Now the blob holds two
-    trees -- the classified triangles' at node 0, the free ones' at ClassBlock::free_root -- and every triangle is in exactly one
+    trees -- the classified triangles' at node 0, the free ones' at ClassBlock::second_root -- and every triangle is in exactly one
     leaf of exactly one of them; the leaf records are grouped the same way; each tree (plus the marker that leads from the first to
     the second) fits the traversal stack.  A scene that is all classified keeps one tree."""
     V, T, M = room_with_a_ball(300, 1200, 8)
@@ -290,9 +290,9 @@ def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
     hdr = raw[:64].view(np.uint32)
     n_tris, n_nodes, bvh_off, leaf_off = int(hdr[0]), int(hdr[6]), int(hdr[7]), int(hdr[8])
     cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 320].view(np.uint32)
-    free_root, first_is_free, n_classified = int(cb[3]), int(cb[68]), int(cb[69])
+    second_root, first_is_free, n_first = int(cb[3]), int(cb[68]), int(cb[69])
     free_max_edge = float(cb[70:71].view(np.float32)[0])
-    assert 0 < free_root < n_nodes and first_is_free == 0 and n_classified == 300
+    assert 0 < second_root < n_nodes and first_is_free == 0 and n_first == 300
     nodes_i = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.int32).reshape(n_nodes, 8)
     leaves = raw[leaf_off:leaf_off + 64 * n_tris].view(np.float32).reshape(n_tris, 16)
     orig = leaves[:, 9].view(np.uint32)
@@ -312,9 +312,9 @@ def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
             todo += [(int(nodes_i[c, 3]), depth + 1), (int(nodes_i[c, 7]), depth + 1)]
         return seen, deepest, inner
     a, depth_a, inner_a = leaves_of(0)
-    b, depth_b, inner_b = leaves_of(free_root)
+    b, depth_b, inner_b = leaves_of(second_root)
     assert sorted(a) == list(range(300)) and sorted(b) == list(range(300, n_tris))
-    assert not (inner_a & inner_b) and len(inner_a) + len(inner_b) == n_nodes and min(inner_b) == free_root
+    assert not (inner_a & inner_b) and len(inner_a) + len(inner_b) == n_nodes and min(inner_b) == second_root
     balanced, k = 0, n_tris
     while k > 2:
         k, balanced = (k + 1) // 2, balanced + 1
@@ -323,6 +323,10 @@ def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
     tri = np.array([t[:3] for t in T])[300:]
     edges = np.concatenate([np.linalg.norm(P[tri[:, i]] - P[tri[:, j]], axis=1) for i, j in ((0, 1), (0, 2), (1, 2))])
     assert abs(free_max_edge - edges.max()) < 1e-5
+    # the sphere around the free triangles: every vertex of the ball inside it, and not much larger than the ball
+    fc, fr = cb[71:74].view(np.float32).astype(np.float64), float(cb[74:75].view(np.float32)[0])
+    ball_pts = P[np.unique(tri)]
+    assert (np.linalg.norm(ball_pts - fc, axis=1) <= fr).all() and fr < 0.35 * 1.8
     # all classified: one tree, as before
     import scenes
     raw = np.frombuffer(pack(pt, *scenes.synthetic_scene(700)), dtype=np.uint8)
@@ -333,4 +337,4 @@ def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
     raw = np.frombuffer(pack(pt, *sliver_scene(300, 5)), dtype=np.uint8)
     hdr = raw[:64].view(np.uint32)
     cb = raw[int(hdr[8]) + 64 * int(hdr[0]):int(hdr[8]) + 64 * int(hdr[0]) + 320].view(np.uint32)
-    assert int(cb[3]) == 0 and int(cb[68]) == 1 and int(cb[69]) == 0
+    assert int(cb[3]) == 0 and int(cb[68]) == 1 and int(cb[69]) == int(hdr[0])

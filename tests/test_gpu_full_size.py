@@ -122,3 +122,92 @@ def test_c3_full_share_of_rank_3(pt, oracle):
         r = np.float32(1.0) / np.float32(s_ + 1)
         ref = (frame * r + (ref * np.float32(s_)) * r).astype(np.float32)
     assert_bit_equal(imgs["fused"][ids], ref, "C3 share of rank 3: sampled pixels vs oracle")
+
+
+@pytest.mark.parametrize("n_room,n_ball", [(972, 20000), (300, 1200)])
+def test_room_with_a_tessellated_ball_at_1080p(pt, oracle, n_room, n_ball):
+    """large walls (normal classes) with a finely tessellated ball (free triangles) -- the mix on which one
+    inflation per ray collapsed (0.1 Grays/s).  Two trees now (pt_bvh.hpp build); at 1920x1080: fused (reference streams) ==
+    the oracle on 2 000 sampled pixels, wavefront (strided) == the oracle on the same pixels in its own mode, the engines agree on
+    every pixel when both run strided streams, ray counts of a pixel range == the oracle's."""
+    from test_bvh_adversarial import room_with_a_ball
+    V, T, M = room_with_a_ball(n_room, n_ball, 8)
+    sc_pt, sc_o = pt.make_scene(V, T, M), oracle.make_scene(V, T, M)
+    spp, n, depth = 3, W * H, 8
+    stride = 2 + 33 * depth
+    ids = np.unique(np.concatenate([np.random.default_rng(n_ball).integers(0, n, 2400), [0, W - 1, n - W, n - 1]])).astype(np.uint32)
+    imgs, rays = {}, {}
+    for name, engine, strided in (("fused", pt.PT_ENGINE_FUSED, False), ("fused-strided", pt.PT_ENGINE_FUSED, True), ("wavefront", pt.PT_ENGINE_WAVEFRONT, True)):
+        with pt.PathTracer(W, H) as tr:
+            tr.set_scene(*sc_pt)
+            tr.set_options(engine=engine, depth=depth, rng_mode=pt.PT_RNG_STRIDED if strided else pt.PT_RNG_SEQUENTIAL, stride=stride, samples_per_pass=3)
+            tr.render(spp)
+            imgs[name], rays[name] = tr.readback(), tr.stats().rays
+    assert_bit_equal(imgs["wavefront"], imgs["fused-strided"], f"room {n_room} + ball: wavefront vs fused, strided streams")
+    assert rays["wavefront"] == rays["fused-strided"] and np.isfinite(imgs["fused"]).all()
+    for name, mode in (("fused", oracle.RNG_SEQUENTIAL), ("wavefront", oracle.RNG_STRIDED)):
+        ref, _, _, _ = oracle.render(oracle.params(W, H, depth=depth, spp=spp, rng_mode=mode, stride=stride), scene=sc_o, pixel_ids=ids)
+        assert_bit_equal(imgs[name][ids], ref, f"room {n_room} + ball {len(T) - n_room}: {name} vs oracle on sampled pixels")
+    first, count = 500 * W + 700, 2048                           # a range that crosses the ball
+    p = oracle.params(W, H, depth=depth, spp=spp, rng_mode=oracle.RNG_STRIDED, stride=stride)
+    _, _, st_ref, _ = oracle.render(p, scene=sc_o, pixel_first=first, n=count)
+    with pt.PathTracer(W, H) as tr:
+        tr.set_scene(*sc_pt)
+        tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=3, pixel_first=first, pixel_count=count)
+        tr.render(spp)
+        st = tr.stats()
+    assert st.rays == st_ref.rays and list(st.rays_per_bounce)[:depth] == [int(x) for x in st_ref.rays_per_bounce[:depth]]
+
+
+@pytest.mark.parametrize("which", ["all-materials", "mirror-extended"])
+def test_c5_at_1080p_64spp(pt, oracle, which):
+    """BASELINE.json configs[4] at its stated size -- all material types, depth 16, 1920x1080 x 64 spp (and the
+    mirror scene under extended shading).  Every form of both engines agrees on every pixel: fused in step, fused out of step
+    (forced), wavefront strided (batches of 16), and -- on the reference's sequential streams -- fused in step, fused out of step
+    and the wavefront engine's rounds; 2 000 sampled pixels of each stream mode == the oracle; per-bounce ray counts of a
+    4 096-pixel range == the oracle's."""
+    extended = which == "mirror-extended"
+    V, T, M = scenes.mirror_scene() if extended else scenes.all_materials_scene()
+    sc_pt, sc_o = pt.make_scene(V, T, M), oracle.make_scene(V, T, M)
+    spp, n, depth = 64, W * H, 16
+    shading = 1 if extended else 0
+    stride = 2 + (2 if extended else 33) * depth
+    ids = np.unique(np.concatenate([np.random.default_rng(64).integers(0, n, 2400), [0, W - 1, n - W, n - 1]])).astype(np.uint32)
+    lib = pt.load_library()
+
+    def render(engine, strided, oos=False, per_pass=16, **extra):
+        import os
+        if oos:
+            os.environ["PT_FUSED_OUT_OF_STEP"] = "1"
+        try:
+            with pt.PathTracer(W, H) as tr:
+                tr.set_scene(*sc_pt)
+                tr.set_options(engine=engine, depth=depth, shading=shading, rng_mode=pt.PT_RNG_STRIDED if strided else pt.PT_RNG_SEQUENTIAL,
+                               stride=stride, samples_per_pass=per_pass, **extra)
+                tr.render(spp)
+                st = tr.stats()
+                return tr.readback(), tr.readback_rng(), st
+        finally:
+            os.environ.pop("PT_FUSED_OUT_OF_STEP", None)
+
+    for strided, mode in ((True, oracle.RNG_STRIDED), (False, oracle.RNG_SEQUENTIAL)):
+        base, base_rng, base_st = render(pt.PT_ENGINE_FUSED, strided)
+        for name, args in (("fused out of step", dict(engine=pt.PT_ENGINE_FUSED, oos=True)),
+                           ("wavefront", dict(engine=pt.PT_ENGINE_WAVEFRONT, per_pass=16 if strided else 64))):
+            img, rng, st = render(strided=strided, **args)
+            assert_bit_equal(img, base, f"{which}, {'strided' if strided else 'sequential'} streams: {name} vs fused in step")
+            assert st.rays == base_st.rays
+            if not strided:
+                assert np.array_equal(rng, base_rng)
+        ref, _, _, _ = oracle.render(oracle.params(W, H, depth=depth, spp=spp, shading=shading, rng_mode=mode, stride=stride), scene=sc_o, pixel_ids=ids)
+        assert_bit_equal(base[ids], ref, f"{which}, {'strided' if strided else 'sequential'} streams: sampled pixels vs oracle")
+    first, count = 333 * W + 900, 4096
+    p = oracle.params(W, H, depth=depth, spp=spp, shading=shading, rng_mode=oracle.RNG_STRIDED, stride=stride)
+    _, _, st_ref, _ = oracle.render(p, scene=sc_o, pixel_first=first, n=count)
+    with pt.PathTracer(W, H) as tr:
+        tr.set_scene(*sc_pt)
+        tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT, depth=depth, shading=shading, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=16,
+                       pixel_first=first, pixel_count=count)
+        tr.render(spp)
+        st = tr.stats()
+    assert st.rays == st_ref.rays and list(st.rays_per_bounce)[:depth] == [int(x) for x in st_ref.rays_per_bounce[:depth]]

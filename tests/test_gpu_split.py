@@ -217,6 +217,24 @@ def test_candidates_are_measured_again_when_the_samples_per_call_change(pt, orac
         last = tr.stats()
         assert last.fused_out_of_step_rays_per_ms > 0
         assert last.fused_out_of_step == (1 if last.fused_out_of_step_rays_per_ms > last.auto_rays_per_ms[1] else 0)
+        # back to one sample per call: that class has been decided before and is NOT measured again (a host that alternates between
+        # 1 sample while the camera moves and 16 when it rests pays for each class once) -- the remembered rates and choice return
+        tr.render(1)
+        again = tr.stats()
+        assert again.auto_rays_per_ms[1] == first.auto_rays_per_ms[1] and again.fused_out_of_step_rays_per_ms == first.fused_out_of_step_rays_per_ms
+        assert again.fused_out_of_step == first.fused_out_of_step
+        tr.render(20)                                      # and the 16..63 class likewise
+        assert tr.stats().auto_rays_per_ms[1] == last.auto_rays_per_ms[1] and tr.stats().fused_out_of_step == last.fused_out_of_step
+        # a Resize to another size and back: the first size's decision is still there (no new measurement), the accumulation restarts
+        tr.Resize(w + 8, h)
+        tr.render(1)
+        tr.Resize(w, h)
+        tr.render(1)
+        back = tr.stats()
+        assert back.frames == 1 and back.auto_rays_per_ms[1] == first.auto_rays_per_ms[1] and back.fused_out_of_step == first.fused_out_of_step
+        tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=12)          # restart for the image check below
+        for spp_ in (1, 1, 1, 2, 16, 16):
+            tr.render(spp_)
         img = tr.readback()
     ref, _, _, _ = oracle.render(oracle.params(w, h, depth=12, spp=3 + 2 + 32), scene=oracle.make_scene(V, T, M))
     assert_bit_equal(img, ref, "all materials, fused engine across two measurements")

@@ -11,9 +11,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pathtracer_amd as pt   # noqa: E402
 import scenes                  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+# scene: a triangle count (scenes.synthetic_scene) or mixed:<room triangles>:<ball facets asked for> (test_bvh_adversarial.room_with_a_ball)
+spec = sys.argv[1] if len(sys.argv) > 1 else "10000"
 engine = pt.PT_ENGINE_WAVEFRONT if (len(sys.argv) < 3 or sys.argv[2] == "wavefront") else pt.PT_ENGINE_FUSED
-V, T, M = scenes.synthetic_scene(n)
+if spec.startswith("mixed:"):
+    from test_bvh_adversarial import room_with_a_ball
+    V, T, M = room_with_a_ball(int(spec.split(":")[1]), int(spec.split(":")[2]), 8)
+else:
+    V, T, M = scenes.synthetic_scene(int(spec))
 lib = pt.load_library()
 out = (C.c_ulonglong * 8)()
 for depth in (1, 10):
