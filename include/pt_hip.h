@@ -99,7 +99,7 @@ typedef struct {
     uint32_t  stride;                    /* STRIDED only */
     uint32_t  shading;                   /* PT_SHADING_REFERENCE (default) or PT_SHADING_EXTENDED */
     uint32_t  flags;                     /* PT_FRAME_* */
-    uint32_t  _reserved[2];              /* zero */
+    uint64_t  primary_lists;             /* 0, or the device address of this pixel range's camera-ray leaf lists (pt_hip_build_primary_lists) */
     pt_float4 origin, top_left, bottom_left, bottom_right;  /* Camera.h:49-77 */
 } pt_frame;
 
@@ -161,6 +161,18 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
  * (the numerators pixel + u that can occur)
  * the short division of PT_FRAME_FAST_DIV equals a / (float)denominator bit for bit.  Synchronises `stream`. */
 int pt_hip_verify_fast_div(uint32_t denominator, int* ok, void* stream);
+
+/* ---- camera rays of BVH scenes (what TraverseScene, kernels.cu:57-69, does for the rays InitializeRays made; no counterpart in the
+ * reference, which loops over all triangles).  Every camera ray of a pixel leaves the camera through the pixel's own patch of the
+ * screen, so ONE conservative walk per pixel writes down the leaves any of them could need (at most PT_PRIMARY_LIST_LEAVES,
+ * else the pixel is marked and walks per ray); with pt_frame.primary_lists set, the extend stage of bounce 0 and the fused
+ * engine test a camera ray against its pixel's listed triangles and take no node step.  Same hits, bit for bit (the bound:
+ * pathtracer_amd/csrc/pt_device.hpp, bvh_collect_pixel).  The lists belong to (scene blob, camera, image size, pixel range): build
+ * them again when any of those changes.  `lists`: pt_hip_primary_lists_bytes(pixel_count) bytes of device memory. ---- */
+#define PT_PRIMARY_LIST_LEAVES 8u
+size_t pt_hip_primary_lists_bytes(uint32_t pixel_count);
+int pt_hip_build_primary_lists(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                               void* lists, void* stream);
 
 /* ---- a1: InitializeRng (kernels.cu:25-30) + RngInit (Functions.cuh:31-38).
  * rng[k] = step^((pixel_first+k)/32)(seed + pixel_first + k), by O(log) GF(2) jump-ahead

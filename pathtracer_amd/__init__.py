@@ -36,6 +36,7 @@ PT_BVH_DEFAULT_MIN_TRIANGLES = 96
 PT_STATS_PUBLIC_WORDS = 64
 PT_STATS_WORDS = PT_STATS_PUBLIC_WORDS + 32 * 16
 PT_NOALLOC_SCRATCH_BYTES = 64 << 20
+PT_PRIMARY_LIST_LEAVES = 8
 
 
 class PathTracerError(RuntimeError):
@@ -72,7 +73,7 @@ class CameraData(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
                 ("depth", C.c_uint32), ("seed", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32),
-                ("shading", C.c_uint32), ("flags", C.c_uint32), ("_reserved", C.c_uint32 * 2),
+                ("shading", C.c_uint32), ("flags", C.c_uint32), ("primary_lists", C.c_uint64),
                 ("origin", Float4), ("top_left", Float4), ("bottom_left", Float4), ("bottom_right", Float4)]
 
 
@@ -165,6 +166,8 @@ SYMBOLS = {
     "pt_hip_scene_has_bvh": (C.c_int, [_VP, _SZ]),
     "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
     "pt_hip_verify_fast_div": (C.c_int, [_U32, C.POINTER(C.c_int), _VP]),
+    "pt_hip_primary_lists_bytes": (_SZ, [_U32]),
+    "pt_hip_build_primary_lists": (C.c_int, [C.POINTER(Frame), _VP, _U32, _U32, _VP, _VP]),
     "pt_hip_rng_seed": (C.c_int, [_FRAMEP, _VP, _VP]),
     "pt_hip_queue_blocks": (_U32, [_U32]),
     "pt_hip_generate": (C.c_int, [_FRAMEP, _U32, _U32, _VP, _VP, _VP, _U32, Queue, _VP, _U32, _VP, _VP]),

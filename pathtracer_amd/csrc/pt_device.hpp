@@ -491,7 +491,11 @@ constexpr int kBvhQuorum = PT_BVH_QUORUM;
 // free_tree: the constants for the walk of the FREE triangles' tree (their worst case kappa_free, in every direction, and nothing
 // for the classes); otherwise for the classified triangles' tree (the classes' graded, in-plane inflation, and nothing for
 // kappa_free).  A scene with one tree holds either only classified or only free triangles (BvhView::first_free).
-__device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 d, float best_t, bool free_tree) {
+// extra_grow / rho_margin (the camera rays' leaf lists, bvh_collect_pixel): the walk stands for a BUNDLE of rays from o whose
+// points at equal parameters are within extra_grow of this ray's and whose unit directions are within rho_margin of its own --
+// every box grows by extra_grow more, and every class is taken rho_margin closer to grazing.
+__device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 d, float best_t, bool free_tree,
+                                                float extra_grow = 0.0f, float rho_margin = 0.0f) {
 	// a zero component would make 0 * inf = NaN in the slabs; a direction error of 1e-20 is far inside the inflation
 	Vec3 dd{ fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x, fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y,
 	         fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z };
@@ -537,7 +541,7 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 		delta_t = bv.slack;
 		for (uint32_t k = 0; k < bv.n_classes; k++) {
 			float4 c = bv.classes[k], ip = bv.in_plane[k];
-			float rho = fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) - c.w;
+			float rho = fabsf(dh.x * c.x + dh.y * c.y + dh.z * c.z) - c.w - rho_margin;
 			float dk = fminf(delta_root, ip.w * s_ray + bv.slack);      // the class's own worst case (its largest triangle's)
 			if (rho >= kBvhRhoMin) dk = fminf(dk, 1.0001f * kBvhKappaRho * __builtin_amdgcn_rcpf(rho) * s_ray + bv.slack);
 			grow.x = fmaxf(grow.x, dk * ip.x); grow.y = fmaxf(grow.y, dk * ip.y); grow.z = fmaxf(grow.z, dk * ip.z);
@@ -545,6 +549,8 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 		}
 		grow.x += bv.slack; grow.y += bv.slack; grow.z += bv.slack;       // (the box arithmetic's own slack is no in-plane quantity)
 	}
+	grow.x += extra_grow; grow.y += extra_grow; grow.z += extra_grow;
+	delta_t += extra_grow;
 	// the same bound holds for the hit distance (t = f * (e1 . q) carries the same 1 / det): |t_true - t| |d| <= delta_t,
 	// so the ray interval is widened to [-dt, best_t + dt] with it
 	r.dt = 1.01f * delta_t / dlen;
@@ -587,8 +593,12 @@ __device__ __forceinline__ void bvh_start(const BvhView& bv, int32_t& cur, int& 
 // walking until it holds a second leaf, so that fewer lanes idle while the slowest lane still looks for its first
 // one -- tried, and slower (see the define).  The order in which leaves are tested cannot
 // change the result: bvh_leaf ranks hits by (t, original index).
+// COLLECT (bvh_collect_pixel): leaves are not tested but written down -- leaf code k of the lane goes to col->list[k * col->stride],
+// col->n counts them (beyond col->cap only counted) -- and best_t stays where the caller put it (FLT_MAX: nothing is pruned by distance).
+struct BvhCollect { uint32_t* list; uint32_t stride, cap, n; float extra_grow, rho_margin; };
+template <bool COLLECT = false>
 __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
-                                          int32_t& cur, int& sp, uint32_t* stack PT_TIME_PARAM) {
+                                          int32_t& cur, int& sp, uint32_t* stack PT_TIME_PARAM, BvhCollect* col = nullptr) {
 	constexpr int32_t kNone = 0;                       // node 0 is the root and never a child, so 0 is free as "no parked leaf"
 	int32_t pend = kNone;
 	PT_TIME_BEGIN();
@@ -635,7 +645,10 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 		if (pend != kNone) bvh_leaf(bv.leaves, (uint32_t)~pend, bv.det_bounded, o, d, best_t, hit_tri);
 		if (cur < 0) {
 			PT_CHECK(((uint32_t)~cur >> 3) + ((uint32_t)~cur & 7u) < bv.n_tris && sp >= 0 && sp <= bv.stack_depth, { cur = kBvhDone; sp = 0; return; });
-			bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
+			if (COLLECT) {
+				if (col->n < col->cap) col->list[(size_t)col->n * col->stride] = (uint32_t)~cur;
+				col->n++;
+			} else bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
 			cur = bvh_pop(stack, sp);
 		}
 		PT_TIME_END(5);
@@ -643,7 +656,8 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 	// the first tree is done (the marker came off the stack in the node walk or after the leaf): on to the second, with the
 	// constants that tree is walked with -- and with the hit distance the first has left, which makes them all the tighter
 	if (bv.second_root != 0u && cur == kBvhSwitch) {
-		r = bvh_ray_setup(bv, o, d, best_t, true);
+		if (COLLECT) r = bvh_ray_setup(bv, o, d, best_t, true, col->extra_grow, col->rho_margin);
+		else r = bvh_ray_setup(bv, o, d, best_t, true);
 		cur = (int32_t)bv.second_root;
 	}
 }
@@ -818,6 +832,7 @@ struct FrameDev {
 	uint32_t shading;
 	uint32_t fast_div;             // PT_FRAME_FAST_DIV: rcp_width / rcp_height may be used (verified per size)
 	float    rcp_width, rcp_height; // correctly rounded 1 / width, 1 / height
+	const uint32_t* primary_lists; // pt_frame::primary_lists (BVH scenes: per pixel of the range, the leaves its camera rays can reach) or null
 	float4   origin, top_left, bottom_left, bottom_right;
 };
 
@@ -829,6 +844,7 @@ inline FrameDev to_dev(const pt_frame& f) {
 	d.depth = f.depth; d.seed = f.seed; d.rng_mode = f.rng_mode; d.stride = f.stride; d.shading = f.shading;
 	d.fast_div = (f.flags & PT_FRAME_FAST_DIV) ? 1u : 0u;
 	d.rcp_width = 1.0f / (float)f.width; d.rcp_height = 1.0f / (float)f.height;      // host IEEE division: correctly rounded
+	d.primary_lists = reinterpret_cast<const uint32_t*>((uintptr_t)f.primary_lists);
 	d.origin = float4{ f.origin.x, f.origin.y, f.origin.z, f.origin.w };
 	d.top_left = float4{ f.top_left.x, f.top_left.y, f.top_left.z, f.top_left.w };
 	d.bottom_left = float4{ f.bottom_left.x, f.bottom_left.y, f.bottom_left.z, f.bottom_left.w };
@@ -920,6 +936,89 @@ __device__ __forceinline__ float4 running_mean(float4 color, float4 prev, uint32
 	float n = (float)frame_number;
 	return float4{ color.x * rcp + prev.x * n * rcp, color.y * rcp + prev.y * n * rcp,
 	               color.z * rcp + prev.z * n * rcp, color.w * rcp + prev.w * n * rcp };
+}
+
+// ---- camera rays of BVH scenes: per pixel, the leaves its camera rays can reach (pt_hip_build_primary_lists) ----
+// All camera rays of a pixel start at the camera and leave through the pixel's own patch of the screen, sample after sample, frame
+// after frame, and each of them walks the tree from the root (18.9 node steps at 10 092 triangles) to end at the same one or two
+// leaves.  So ONE walk per pixel -- for as long as camera, scene and image size stay -- writes down every leaf ANY of the pixel's
+// rays could need, and a camera ray then tests the triangles of those leaves and takes no node step at all.
+// Conservative by reduction to the walk's own bound (pt_bvh.hpp): a ray R' of the pixel that the fp32 test accepts on triangle k
+// passes, at some parameter t, within delta_k of k.  The unnormalised direction is affine in the two jitter draws, so over the
+// patch it stays in the parallelogram of the four corner directions; the distance of D / |D| (all four lanes, as kernels.cu:44
+// normalises) from a fixed point is quasi-convex in D (its sublevel sets are cones over spherical caps), hence largest at a
+// corner: chord = max_i |d_i - d_c| over the corners bounds |d' - d_c| for every ray of the pixel (fp32 rounding of the traced
+// direction: 1e-6, covered by the margins below).  R' and the centre ray R_c share their origin, so |R'(t) - R_c(t)| <= t chord,
+// and t |d'| cannot exceed the reach of the scene from the camera: R_c passes within delta_k + extra of k, extra = chord * reach /
+// |d'|.  The walk of R_c with every box grown by `extra` more, no pruning by distance (best_t = FLT_MAX), and every class taken
+// chord / |d| closer to grazing (rho is 1-Lipschitz in the unit direction; Dunkl-Williams for the normalisation) therefore reaches
+// the leaf of k.  A pixel whose walk finds more than PT_PRIMARY_LIST_LEAVES leaves is marked and keeps walking per ray.
+constexpr uint32_t kPrimaryListCap = PT_PRIMARY_LIST_LEAVES;
+constexpr uint32_t kPrimaryListWalk = 0xFFFFFFFFu;          // lists[pixel]: this pixel's camera rays walk the tree
+
+struct PixelCone { Vec3 dc; float chord, dmin; };
+__device__ __forceinline__ PixelCone pixel_cone(const FrameDev& f, uint32_t px, uint32_t py) {
+	// the patch: (x + u) / width with u in (0, 1], rounded; IEEE division is monotonic (and the fast form returns the same bits)
+	const float xs[2] = { (float)px / (float)f.width, ((float)px + 1.0f) / (float)f.width };
+	const float ys[2] = { (float)py / (float)f.height, ((float)py + 1.0f) / (float)f.height };
+	const float4 bl = f.bottom_left, br = f.bottom_right, tl = f.top_left;
+	float4 c[4];
+	float4 mean = float4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const float x = xs[k & 1], y = ys[k >> 1];
+		float4 p = float4{ (bl.x + (br.x - bl.x) * x) + (tl.x - bl.x) * y, (bl.y + (br.y - bl.y) * x) + (tl.y - bl.y) * y,
+		                   (bl.z + (br.z - bl.z) * x) + (tl.z - bl.z) * y, (bl.w + (br.w - bl.w) * x) + (tl.w - bl.w) * y };
+		const float inv = 1.0f / __builtin_sqrtf(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w);
+		c[k] = float4{ p.x * inv, p.y * inv, p.z * inv, p.w * inv };
+		mean.x += 0.25f * c[k].x; mean.y += 0.25f * c[k].y; mean.z += 0.25f * c[k].z; mean.w += 0.25f * c[k].w;
+	}
+	float chord2 = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const float ex = c[k].x - mean.x, ey = c[k].y - mean.y, ez = c[k].z - mean.z, ew = c[k].w - mean.w;
+		chord2 = fmaxf(chord2, ex * ex + ey * ey + ez * ez + ew * ew);
+	}
+	PixelCone pc;
+	pc.dc = Vec3{ mean.x, mean.y, mean.z };
+	pc.chord = 1.001f * __builtin_sqrtf(chord2) + 4e-6f;                  // (+ the rounding of the traced directions and of these)
+	pc.dmin = __builtin_sqrtf(mean.x * mean.x + mean.y * mean.y + mean.z * mean.z) - pc.chord;      // |d'| >= |d_c| - chord over the patch
+	return pc;
+}
+
+// One pixel per lane; every lane of the wave calls it (bvh_round's ballots), `active` false: takes part idly.  lists: pixel_count
+// counts, then PT_PRIMARY_LIST_LEAVES rows of pixel_count leaf codes.  `stack`: the lane's column of the traversal stack.
+__device__ __forceinline__ void bvh_collect_pixel(const BvhView& bv, const FrameDev& f, bool active, uint32_t px, uint32_t py, uint32_t li,
+                                                  uint32_t* __restrict__ lists, uint32_t pixel_count, uint32_t* stack) {
+	const PixelCone pc = pixel_cone(f, px, py);
+	// a cone too wide for the bound to mean anything (a camera inside out, a 2 x 2 image): the pixel walks per ray
+	const bool ok = active && pc.dmin > 0.05f && pc.chord < 0.05f;
+	const float reach = bv.s_bound + (bv.kappa_root * bv.s_bound + bv.slack);          // |origin - hit| <= |origin - centre| + radius + delta
+	BvhCollect col{ lists + (size_t)pixel_count + li, pixel_count, kPrimaryListCap, 0u,
+	                ok ? 1.01f * pc.chord * reach / pc.dmin + 1e-6f : 0.0f, ok ? 1.01f * pc.chord / pc.dmin : 0.0f };
+	const Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
+	float best = FLT_MAX;
+	uint32_t tri = kNoHit;
+	BvhRay r{};
+	int32_t cur = kBvhDone;
+	int sp = 0;
+	if (ok) {
+		r = bvh_ray_setup(bv, o, pc.dc, best, bv.first_free, col.extra_grow, col.rho_margin);
+		bvh_start(bv, cur, sp, stack);
+	}
+	PT_TIME_NULL();
+	while (__any(cur != kBvhDone)) bvh_round<true>(bv, r, o, pc.dc, best, tri, cur, sp, stack PT_TIME_ARG, &col);
+	if (active) lists[li] = ok && col.n <= kPrimaryListCap ? col.n : kPrimaryListWalk;
+}
+
+// The camera ray of pixel li against its listed leaves: the same tests, ranked the same way, as the walk would have made among
+// (at least) the leaves it would have reached.  False: the pixel has no list (kPrimaryListWalk), walk.
+__device__ __forceinline__ bool bvh_list_intersect(const BvhView& bv, const uint32_t* __restrict__ lists, uint32_t pixel_count, uint32_t li,
+                                                   Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri) {
+	const uint32_t n = lists[li];
+	if (n > kPrimaryListCap) return false;
+	for (uint32_t k = 0; k < n; k++) bvh_leaf(bv.leaves, lists[(size_t)(1u + k) * pixel_count + li], bv.det_bounded, o, d, best_t, hit_tri);
+	return true;
 }
 
 } // namespace ptd

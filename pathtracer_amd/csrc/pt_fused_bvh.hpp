@@ -165,6 +165,12 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 				b = 0;
 				has_ray = true;
 				fresh = true;
+				// the pixel's leaf list (pt_device.hpp, bvh_collect_pixel): the camera ray is finished right here, without a walk, and
+				// waits for its shade like any finished ray
+				if (f.primary_lists != nullptr) {
+					tri = kNoHit;
+					if (bvh_list_intersect(c.bv, f.primary_lists, f.pixel_count, li, o, d, best, tri)) { n_rays++; fresh = false; }
+				}
 			}
 			if (fresh) {
 				n_rays++;
@@ -173,7 +179,12 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 				bvh_start(c.bv, cur, sp, stack);
 			}
 		}
-		if (!__any(cur != kBvhDone)) break;      // after a service nobody walks only if nobody had anything left to do
+		if (!__any(cur != kBvhDone)) {
+			// nobody walks: either nobody has anything left to do, or finished rays wait for their shade (camera rays that their
+			// pixels' leaf lists finished without a walk) -- the next trip serves them
+			if (__any(has_ray || have_pixel) || !exhausted) continue;
+			break;
+		}
 		PT_TIME_NULL();
 		bvh_round(c.bv, r, o, d, best, tri, cur, sp, stack PT_TIME_ARG);
 	}

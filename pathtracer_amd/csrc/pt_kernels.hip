@@ -279,7 +279,7 @@ template <bool FIRST, bool BVH>
 __global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 camera, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                    const float4* __restrict__ qa, const float4* __restrict__ qb,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t capacity,
-                                                   uint2* __restrict__ hit) {
+                                                   uint2* __restrict__ hit, const uint32_t* __restrict__ lists, uint32_t list_pixels) {
 	extern __shared__ float4 s_tris[];
 	if (!scene_guard(scene, n_tris, BVH)) return;
 	const float4* g_tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
@@ -293,6 +293,35 @@ __global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 came
 	if (single) {
 		for (uint32_t k = threadIdx.x; k < n_tris * 4; k += kBlock) s_tris[k] = g_tris[k];
 		__syncthreads();
+	}
+	if (BVH && FIRST && lists != nullptr) {
+		// camera rays with their pixels' leaf lists (pt_device.hpp, bvh_collect_pixel): no node steps; the few pixels whose lists
+		// overflowed walk, the wave's lanes together (path id == slot at bounce 0, local pixel = path id % pixel_count)
+		uint32_t* stack = s_stack + threadIdx.x;
+		const Vec3 o{ origin.x, origin.y, origin.z };
+		for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
+			const uint32_t q = queue_slot(j0, G) + threadIdx.x;
+			const bool active = j0 + threadIdx.x < count && q < capacity;
+			Vec3 d{ 0, 0, 0 };
+			float best = FLT_MAX;
+			uint32_t tri = kNoHit;
+			bool walk = false;
+			if (active) {
+				const float4 b = qb[q];
+				d = Vec3{ b.x, b.y, b.z };
+				walk = !bvh_list_intersect(bv, lists, list_pixels, q % list_pixels, o, d, best, tri);
+			}
+			if (__any(walk)) {
+				BvhRay r{};
+				int32_t cur = kBvhDone;
+				int sp = 0;
+				if (walk) { r = bvh_ray_setup(bv, o, d, best, bv.first_free); bvh_start(bv, cur, sp, stack); }
+				PT_TIME_NULL();
+				while (__any(cur != kBvhDone)) bvh_round(bv, r, o, d, best, tri, cur, sp, stack PT_TIME_ARG);
+			}
+			if (active) hit[q] = uint2{ __float_as_uint(best), tri };
+		}
+		return;
 	}
 	if (BVH) {
 		__shared__ uint32_t s_next;
@@ -322,6 +351,21 @@ __global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 came
 			}
 		}
 		if (active) hit[q] = uint2{ __float_as_uint(best), tri };
+	}
+}
+
+// pt_hip_build_primary_lists: one pixel per lane, the conservative walk of its camera rays' cone (pt_device.hpp, bvh_collect_pixel)
+__global__ __launch_bounds__(kBlock, 8) void k_primary_lists(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
+                                                             uint32_t* __restrict__ lists) {
+	extern __shared__ float4 s_dyn[];
+	if (!scene_guard(scene, n_tris, true)) return;
+	uint32_t* stack = reinterpret_cast<uint32_t*>(s_dyn) + threadIdx.x;
+	const BvhView bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
+	for (uint32_t li0 = blockIdx.x * kBlock; li0 < f.pixel_count; li0 += gridDim.x * kBlock) {
+		const uint32_t li = li0 + threadIdx.x;
+		const bool active = li < f.pixel_count;
+		const uint32_t i = f.pixel_first + (active ? li : 0u);
+		bvh_collect_pixel(bv, f, active, i % (uint32_t)f.width, i / (uint32_t)f.width, li, lists, f.pixel_count, stack);
 	}
 }
 
@@ -810,7 +854,8 @@ void launch_extend(const FrameDev& f, uint32_t bounce, const void* scene_blob, c
 	bool bvh = scene_has_bvh(si);
 	guard_ready();
 	size_t lds = bvh ? (size_t)bvh_stack_depth(si.n_tris) * kBlock * sizeof(uint32_t) : extend_lds_bytes(si.n_tris);
-#define PT_EXT(FIRST, BVH) hipLaunchKernelGGL((k_extend<FIRST, BVH>), grid, block, lds, s, f.origin, f.origin, sc, si.n_tris, si.n_mats, qa, qb, counts, capacity, hit)
+#define PT_EXT(FIRST, BVH) hipLaunchKernelGGL((k_extend<FIRST, BVH>), grid, block, lds, s, f.origin, f.origin, sc, si.n_tris, si.n_mats, qa, qb, counts, capacity, hit, \
+	f.primary_lists, f.pixel_count)
 	if (bounce == 0) { if (bvh) PT_EXT(true, true); else PT_EXT(true, false); }
 	else { if (bvh) PT_EXT(false, true); else PT_EXT(false, false); }
 #undef PT_EXT
@@ -1031,6 +1076,23 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 		r[2] = r[3] = 0.0f;
 		r[4] = materials[k].color.x; r[5] = materials[k].color.y; r[6] = materials[k].color.z; r[7] = materials[k].color.w;
 	}
+	return PT_OK;
+}
+
+size_t pt_hip_primary_lists_bytes(uint32_t pixel_count) { return (size_t)pixel_count * (1u + PT_PRIMARY_LIST_LEAVES) * sizeof(uint32_t); }
+
+int pt_hip_build_primary_lists(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, void* lists, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!scene_blob || !lists) return fail(PT_ERR_INVALID, "build_primary_lists: null pointer");
+	if (!(frame->flags & PT_FRAME_SCENE_BVH)) return fail(PT_ERR_INVALID, "build_primary_lists: the lists are leaves of the scene's BVH (PT_FRAME_SCENE_BVH)");
+	if (frame->pixel_count == 0) return PT_OK;
+	guard_ready();
+	FrameDev f = to_dev(*frame);
+	f.primary_lists = nullptr;
+	const size_t lds = (size_t)bvh_stack_depth(n_triangles) * kBlock * sizeof(uint32_t);
+	hipLaunchKernelGGL(k_primary_lists, dim3(grid_for(frame->pixel_count)), dim3(kBlock), lds, (hipStream_t)stream, f, (const unsigned char*)scene_blob,
+	                   n_triangles, n_materials, (uint32_t*)lists);
+	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
 

@@ -96,7 +96,13 @@ class PathTracer final : public IPathTracer {
 		void* workspace = nullptr;      // wavefront queues
 		void* image = nullptr;          // SAMPLE split: the combined image, _pitch float4
 		void* stacked = nullptr;        // SAMPLE split: shard-major staging of a combine (V x slice, or V x pitch on a gather root)
+		void* lists = nullptr;          // BVH scenes: per pixel, the leaves its camera rays can reach (pt_hip_build_primary_lists)
 	} _dev;
+	// The lists hold for one (scene, camera, size, pixel range): every restart of the accumulation drops them, and they are
+	// built again once the accumulation is worth it -- a build costs about two samples' worth of camera rays, so a host that
+	// moves its camera every frame never pays for one (kListsFromSample).  PT_PRIMARY_LISTS=off in the environment: never.
+	bool _listsValid = false;
+	static constexpr uint32_t kListsFromSample = 3;
 	size_t _workspaceBytes = 0, _stackedBytes = 0;
 	uint32_t _nTris = 0, _nMats = 0;
 	bool _sceneHasBvh = false;          // recorded when the scene is packed (pt_hip_scene_has_bvh), passed with every frame
@@ -216,7 +222,7 @@ public:
 		if (_stream) pt_hip_stream_synchronize(_stream);
 		if (_comm) pt_hip_comm_destroy(_comm);
 		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.scene);
-		pt_hip_free(_dev.stats); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked);
+		pt_hip_free(_dev.stats); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked); pt_hip_free(_dev.lists);
 		pt_hip_event_destroy(_evStart); pt_hip_event_destroy(_evStop);
 		for (uint32_t k = 0; k < kSideStreams; k++) {
 			if (_side[k]) { pt_hip_stream_synchronize(_side[k]); pt_hip_stream_destroy(_side[k]); }
@@ -608,6 +614,7 @@ private:
 		f.depth = _opt.depth; f.seed = _opt.seed; f.rng_mode = _opt.rng_mode; f.stride = _opt.stride;
 		f.shading = _opt.shading;
 		f.flags = _frameFlags | (_sceneHasBvh ? PT_FRAME_SCENE_BVH : 0u);
+		f.primary_lists = _sceneHasBvh && _listsValid ? (uint64_t)(uintptr_t)_dev.lists : 0ull;
 		f.origin = _camera.GetPosition();
 		f.top_left = _camera.GetTopLeft();
 		f.bottom_left = _camera.GetBottomLeft();
@@ -662,8 +669,9 @@ private:
 		_ranks = l.ranks; _pixelFirst = l.pixel_first; _pixelCount = l.pixel_count;
 		_vShards = l.v_shards; _localShards = l.local_shards; _slice = l.slice; _pitch = l.pitch;
 		_imageCurrent = false;
-		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked);
-		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _dev.image = nullptr; _dev.stacked = nullptr;
+		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked); pt_hip_free(_dev.lists);
+		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _dev.image = nullptr; _dev.stacked = nullptr; _dev.lists = nullptr;
+		_listsValid = false;
 		_workspaceBytes = 0; _stackedBytes = 0;
 		// the short division of the ray set-up is used only for sizes it is verified for (exhaustively, on the device)
 		int okW = 0, okH = 0;
@@ -684,6 +692,7 @@ private:
 	// PathTracer.cu:235-244
 	int _InitializeRendering() {
 		_shouldRestartRendering = false;
+		_listsValid = false;                         // the camera, the scene or the pixel range may have changed
 		_frameNumber = 0;
 		_totalMs = 0.0; _renders = 0;
 		_imageCurrent = false;
@@ -766,6 +775,13 @@ private:
 		_candInFlight = cand;
 		_imageCurrent = false;
 		PT_TRY(pt_hip_event_record(_evStart, _stream));
+		if (_sceneHasBvh && !_listsValid && (uint64_t)_frameNumber + samples >= kListsFromSample && !std::getenv("PT_PRIMARY_LISTS")) {
+			// (inside the timed region: the device time the statistics report includes it)
+			if (!_dev.lists) PT_TRY(pt_hip_malloc(&_dev.lists, pt_hip_primary_lists_bytes(_pixelCount)));
+			PT_TRY(pt_hip_build_primary_lists(&f, _dev.scene, _nTris, _nMats, _dev.lists, _stream));
+			_listsValid = true;
+			f.primary_lists = (uint64_t)(uintptr_t)_dev.lists;
+		}
 		// Several local shards through the fused engine (strided streams: the stream words are only READ, and each shard
 		// writes a mean of its own).  Brute-force scenes in step: all of them in ONE launch (pt_hip_render_fused_shards) --
 		// a launch per shard costs 0.06 ms of a 1.0 ms step (tools/split_cost.py, 1080p, 8 shards x 8 samples).
