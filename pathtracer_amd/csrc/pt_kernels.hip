@@ -369,6 +369,89 @@ __global__ __launch_bounds__(kBlock, 8) void k_primary_lists(FrameDev f, const u
 	}
 }
 
+// BVH scenes with camera-ray leaf lists: InitializeRays + the camera rays' TraverseScene + their Intersect (kernels.cu:32-55, 57-69,
+// 71-94) in ONE launch -- a path is made, tested against its pixel's listed triangles, shaded and, if it goes on, pushed into the
+// block's own slots of the bounce-1 queue, all from registers: the bounce-0 queue (16 B per path written and read back twice) and
+// its hit array (8 B written and read) never exist, and three launches are one.  Paths are the identity queue's: block b owns
+// path ids ((r G + b) 256 + t), counts[b] of them (k_set_count).  A pixel whose list overflowed (kPrimaryListWalk) needs a walk: its
+// path is written out as a queue entry in the full format of a later bounce (origin, direction, best_t = FLT_MAX, throughput 1) into
+// the block's own slots of queue 0, counted in over_count[b], and the ordinary extend and shade stages finish those few behind
+// this kernel (launch_shade append) -- no traversal code, no stack here.
+constexpr uint32_t kCameraMaxSamples = 64;           // sample matrices staged in LDS (8 KiB); passes of more samples take the staged stages
+template <bool STRIDED>
+__global__ __launch_bounds__(kBlock, 8) void k_camera_lists(FrameDev f, const uint32_t* __restrict__ smat, uint32_t n_samples, const uint32_t* __restrict__ rng_in,
+                                                            const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
+                                                            const uint32_t* __restrict__ count_ptr, uint32_t capacity,
+                                                            float4* __restrict__ wa, float4* __restrict__ wb, float4* __restrict__ wc, uint32_t* __restrict__ wpid,
+                                                            uint32_t* __restrict__ over_count,
+                                                            float4* __restrict__ oa, float4* __restrict__ ob, float4* __restrict__ oc, uint32_t* __restrict__ opid,
+                                                            uint32_t* __restrict__ count_out,
+                                                            float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out) {
+	__shared__ uint32_t s_jump[1024];
+	__shared__ uint32_t s_mat[STRIDED ? 32 * kCameraMaxSamples : 1];
+	__shared__ uint32_t s_out, s_traced, s_over;
+	if (!scene_guard(scene, n_tris, true)) return;
+	stage_jump31(s_jump);
+	if (STRIDED) for (uint32_t t = threadIdx.x; t < 32u * n_samples; t += kBlock) s_mat[t] = smat[t];
+	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; s_over = 0; }
+	const BvhView bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
+	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
+	const float4* mats = tris + (size_t)n_tris * 4;
+	__syncthreads();
+	ShadeCtx c{ f, tris, mats, s_jump, n_tris, bv.det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
+	const uint32_t G = gridDim.x, lane = threadIdx.x & 63u;
+	const uint32_t count = count_ptr[blockIdx.x];
+	const bool extended = f.shading == PT_SHADING_EXTENDED;
+	const Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
+	const float inv_pixels = 1.0f / (float)f.pixel_count;
+	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
+		const uint32_t q = queue_slot(j0, G) + threadIdx.x;          // == the path id
+		const bool active = j0 + threadIdx.x < count && q < capacity;
+		PathNext r;
+		r.pid = q;
+		bool over = false;
+		Vec3 d{ 0, 0, 0 };
+		uint32_t rng = 0;
+		if (active) {
+			// sample and local pixel of path q = s * pixel_count + li: a float estimate of the quotient (s < 2^16, so it is off by one at most) and one correction either way
+			uint32_t s = STRIDED ? (uint32_t)((float)q * inv_pixels) : 0u;
+			int32_t rem = (int32_t)(q - s * f.pixel_count);
+			if (STRIDED) {
+				if (rem < 0) { s--; rem += (int32_t)f.pixel_count; }
+				else if ((uint32_t)rem >= f.pixel_count) { s++; rem -= (int32_t)f.pixel_count; }
+			}
+			const uint32_t li = (uint32_t)rem;
+			const uint32_t i = f.pixel_first + li;
+			rng = rng_in[li];
+			if (STRIDED) rng = mat_apply_lds(s_mat + 32u * s, rng);
+			d = primary_direction(f, i % (uint32_t)f.width, i / (uint32_t)f.width, rng);
+			float best = FLT_MAX;
+			uint32_t tri = kNoHit;
+			over = !bvh_list_intersect(bv, f.primary_lists, f.pixel_count, li, o, d, best, tri);
+			if (!over) shade_lane<true, false, true, false>(c, extended, last_bounce, q, uint2{ __float_as_uint(best), tri },
+			                                                float4{ d.x, d.y, d.z, __uint_as_float(rng) }, nullptr, nullptr, nullptr, r);
+		}
+		queue_push<false, false>(c, last_bounce, r, oa, ob, oc, opid, nullptr);
+		// the paths that need a walk: compacted like the others, into the block's own slots of queue 0
+		const unsigned long long over_mask = __ballot(over);
+		if (over_mask != 0ull) {
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(&s_over, (uint32_t)__popcll(over_mask));
+			base = __shfl(base, 0, 64);
+			if (over) {
+				const uint32_t j = base + (uint32_t)__popcll(over_mask & ((1ull << lane) - 1ull));
+				const uint32_t pos = ((j / kQueueBlock) * G + blockIdx.x) * kQueueBlock + (j % kQueueBlock);
+				wa[pos] = float4{ o.x, o.y, o.z, d.x };
+				wb[pos] = float4{ d.y, d.z, FLT_MAX, __uint_as_float(rng) };
+				wc[pos] = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+				wpid[pos] = q;
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { count_out[blockIdx.x] = s_out; over_count[blockIdx.x] = s_over; }
+}
+
 template <bool FIRST, bool SCENE_LDS, bool EXTEND>
 __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned char* __restrict__ scene,
                                                   uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce, uint32_t scene_bvh,
@@ -381,7 +464,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
                                                   uint2* __restrict__ ohit,
                                                   uint32_t* __restrict__ count_out,
                                                   float4* __restrict__ radiance, unsigned char* __restrict__ lit,
-                                                  uint32_t* __restrict__ rng_out) {
+                                                  uint32_t* __restrict__ rng_out, uint32_t append) {
 	static_assert(!EXTEND || SCENE_LDS, "the fused extend intersects against the LDS copy of the scene");
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
@@ -400,7 +483,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 		tris = s_scene; mats = s_scene + nt4;
 	}
 	__shared__ uint32_t s_out, s_traced;
-	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; }
+	// append: the block's slots of the output queue already hold count_out[block] paths (k_camera_lists put them there); go on behind them
+	if (threadIdx.x == 0) { s_out = append ? count_out[blockIdx.x] : 0u; s_traced = 0; }
 	__syncthreads();
 	ShadeCtx c{ f, tris, mats, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
 	shade_block<FIRST, EXTEND, false>(c, last_bounce, count_ptr[blockIdx.x], qa, qb, qc, qpid, hit, oa, ob, oc, opid, ohit);
@@ -1173,7 +1257,10 @@ int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob
 
 static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneInfo& si, uint32_t bounce,
                         pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
-                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s) {
+                        pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s,
+                        bool append = false, bool as_later_bounce = false) {
+	// append / as_later_bounce: the camera rays k_camera_lists could not finish (their pixels' lists overflowed) come as a queue in
+	// the full format of a later bounce, are shaded as bounce `bounce` (0) and join the paths that kernel already queued
 	uint32_t last = (bounce + 1 >= f.depth) ? 1u : 0u;
 	bool lds = shade_scene_in_lds(si);
 	bool extend = hit_out != nullptr;
@@ -1183,8 +1270,8 @@ static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneIn
 	guard_ready();
 #define PT_SHADE(FIRST, LDS, EXT) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, si.bvh ? 1u : 0u, \
 	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
-	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng)
-	if (bounce == 0) { if (extend) PT_SHADE(true, true, true); else if (lds) PT_SHADE(true, true, false); else PT_SHADE(true, false, false); }
+	(float4*)out.a, (float4*)out.b, (float4*)out.c, out.pid, (uint2*)hit_out, count_out, (float4*)radiance, (unsigned char*)lit, rng, append ? 1u : 0u)
+	if (bounce == 0 && !as_later_bounce) { if (extend) PT_SHADE(true, true, true); else if (lds) PT_SHADE(true, true, false); else PT_SHADE(true, false, false); }
 	else { if (extend) PT_SHADE(false, true, true); else if (lds) PT_SHADE(false, true, false); else PT_SHADE(false, false, false); }
 #undef PT_SHADE
 	HIP_TRY(hipGetLastError());
@@ -1288,13 +1375,31 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 			if (stats && last_pass) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.ray_counts, G, frame->depth, (unsigned long long*)stats);
 		} else {
 			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
-			if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
+			// camera rays through their pixels' leaf lists: made, intersected, shaded and queued in one launch (k_camera_lists)
+			const bool camera_fused = scene_has_bvh(si) && f.primary_lists != nullptr && ns <= kCameraMaxSamples && !std::getenv("PT_CAMERA_STAGED");
+			if (!camera_fused) { if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc; }
+			else {
+				uint32_t* over = w.counts + (size_t)(PT_MAX_DEPTH + 1) * G;          // a spare row of the counters: paths whose pixels have no list
+				if (!sequential) hipLaunchKernelGGL(k_sample_matrices, dim3(ns), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
+				const uint32_t last0 = frame->depth <= 1u ? 1u : 0u;
+#define PT_CAM(STR) hipLaunchKernelGGL(k_camera_lists<STR>, dim3(G), dim3(kBlock), 0, s, f, (const uint32_t*)w.smat, ns, (const uint32_t*)rng, (const unsigned char*)scene_blob, \
+				si.n_tris, si.n_mats, last0, (const uint32_t*)w.counts, (uint32_t)paths_cap, w.a[0], w.b[0], w.c[0], w.pid[0], over, \
+				w.a[1], w.b[1], w.c[1], w.pid[1], w.counts + G, w.radiance, w.lit, sequential ? rng : nullptr)
+				if (sequential) PT_CAM(false); else PT_CAM(true);
+#undef PT_CAM
+				FrameDev fw = f;
+				fw.primary_lists = nullptr;
+				launch_extend(fw, 1, scene_blob, si, w.a[0], w.b[0], over, (uint32_t)paths_cap, w.hit[0], s);       // (bounce 1's form: rays with an origin of their own)
+				pt_queue qi{ w.a[0], w.b[0], w.c[0], w.pid[0] }, qo{ w.a[1], w.b[1], w.c[1], w.pid[1] };
+				if (int rc = launch_shade(f, scene_blob, si, 0, qi, w.hit[0], over, (uint32_t)paths_cap, qo, nullptr, w.counts + G, w.radiance, w.lit,
+				                          sequential ? rng : nullptr, s, true, true)) return rc;
+			}
 			// BVH scenes: the first bounces staged (camera rays, and the bulk of the bounced ones, each in an extend of its own at full
 			// occupancy, each shade a streaming pass), the RAYS of bounce kTailEntryBounce and everything after them in one persistent launch
 			const char* tail_env = std::getenv("PT_WAVEFRONT_TAIL");             // measurement / test knob: "off" = every bounce staged, a digit = the tail's entry bounce
 			const uint32_t tail_from = !scene_has_bvh(si) || (tail_env && tail_env[0] == 'o') ? 0xFFFFFFFFu : tail_env ? (uint32_t)std::atoi(tail_env) : kTailEntryBounce;
 			if (tail_from >= 1u && tail_from < frame->depth && tail_from < 0xFFFFFFFFu) {
-				for (uint32_t b = 0; b < tail_from; b++) {
+				for (uint32_t b = camera_fused ? 1u : 0u; b < tail_from; b++) {
 					int in = b & 1, out = in ^ 1;
 					launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
 					pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
@@ -1307,7 +1412,7 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 				                   (const float4*)w.a[in], (const float4*)w.b[in], (const float4*)w.c[in], (const uint32_t*)w.pid[in],
 				                   w.counts, (uint32_t)paths_cap, w.radiance, w.lit, sequential ? rng : nullptr);
 			} else
-			for (uint32_t b = 0; b < frame->depth; b++) {
+			for (uint32_t b = camera_fused ? 1u : 0u; b < frame->depth; b++) {
 				int in = b & 1, out = in ^ 1;
 				launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
 				pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
