@@ -164,9 +164,10 @@ int pt_hip_verify_fast_div(uint32_t denominator, int* ok, void* stream);
 
 /* ---- camera rays of BVH scenes (what TraverseScene, kernels.cu:57-69, does for the rays InitializeRays made; no counterpart in the
  * reference, which loops over all triangles).  Every camera ray of a pixel leaves the camera through the pixel's own patch of the
- * screen, so ONE conservative walk per pixel writes down the leaves any of them could need (at most PT_PRIMARY_LIST_LEAVES,
- * else the pixel is marked and walks per ray); with pt_frame.primary_lists set, the extend stage of bounce 0 and the fused
- * engine test a camera ray against its pixel's listed triangles and take no node step.  Same hits, bit for bit (the bound:
+ * screen, so ONE conservative walk per pixel writes down the triangles any of them could hit (at most PT_PRIMARY_LIST_LEAVES
+ * one-triangle leaf codes, else the pixel is marked and walks per ray); with pt_frame.primary_lists set, the extend stage of bounce 0,
+ * the wavefront render's fused camera kernel and the fused engine test a camera ray against its pixel's listed triangles and take
+ * no node step.  Same hits, bit for bit (the bound:
  * pathtracer_amd/csrc/pt_device.hpp, bvh_collect_pixel).  The lists belong to (scene blob, camera, image size, pixel range): build
  * them again when any of those changes.  `lists`: pt_hip_primary_lists_bytes(pixel_count) bytes of device memory. ---- */
 #define PT_PRIMARY_LIST_LEAVES 8u

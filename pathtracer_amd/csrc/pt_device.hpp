@@ -595,7 +595,11 @@ __device__ __forceinline__ void bvh_start(const BvhView& bv, int32_t& cur, int& 
 // change the result: bvh_leaf ranks hits by (t, original index).
 // COLLECT (bvh_collect_pixel): leaves are not tested but written down -- leaf code k of the lane goes to col->list[k * col->stride],
 // col->n counts them (beyond col->cap only counted) -- and best_t stays where the caller put it (FLT_MAX: nothing is pruned by distance).
-struct BvhCollect { uint32_t* list; uint32_t stride, cap, n; float extra_grow, rho_margin; };
+struct BvhCollect {
+	uint32_t* list; uint32_t stride, cap, n; float extra_grow, rho_margin;
+	Vec3 o; Vec3 corner[4]; float dmax;         // the pixel's patch: camera position, the four (unnormalised) corner directions, the margin unit of corners_can_hit
+};
+__device__ __forceinline__ bool corners_can_hit(const Vec3* corner, float dmax, Vec3 e0, Vec3 e1, Vec3 s, Vec3 q);
 template <bool COLLECT = false>
 __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
                                           int32_t& cur, int& sp, uint32_t* stack PT_TIME_PARAM, BvhCollect* col = nullptr) {
@@ -646,8 +650,20 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 		if (cur < 0) {
 			PT_CHECK(((uint32_t)~cur >> 3) + ((uint32_t)~cur & 7u) < bv.n_tris && sp >= 0 && sp <= bv.stack_depth, { cur = kBvhDone; sp = 0; return; });
 			if (COLLECT) {
-				if (col->n < col->cap) col->list[(size_t)col->n * col->stride] = (uint32_t)~cur;
-				col->n++;
+				// triangle by triangle (a list entry is a leaf code of ONE triangle), and only those the pixel's camera rays can hit at
+				// all: corners_can_hit, the rejection tests of Functions.cuh:72-86 at the patch's four corners (what primary_need_mask
+				// does for scenes in LDS) -- it drops the far side of every closed object (faces turned away: det < EPSILON for the
+				// whole patch) and the leaf-mates and box-neighbours the cone merely passes
+				const uint32_t first = (uint32_t)~cur >> 3, count = ((uint32_t)~cur & 7u) + 1u;
+				for (uint32_t k = 0; k < count; k++) {
+					const float4* rec = bv.leaves + (size_t)(first + k) * 4;
+					const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+					const Vec3 v0{ r0.x, r0.y, r0.z }, e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x };
+					const Vec3 sv{ col->o.x - v0.x, col->o.y - v0.y, col->o.z - v0.z };
+					if (!corners_can_hit(col->corner, col->dmax, e0, e1, sv, cross3(sv, e0))) continue;
+					if (col->n < col->cap) col->list[(size_t)col->n * col->stride] = (first + k) << 3;
+					col->n++;
+				}
 			} else bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
 			cur = bvh_pop(stack, sp);
 		}
@@ -896,6 +912,26 @@ __device__ __forceinline__ Vec3 screen_point(const FrameDev& f, float xs, float 
 }
 __device__ __forceinline__ float l1norm(Vec3 v) { return fabsf(v.x) + fabsf(v.y) + fabsf(v.z); }
 
+// one triangle against a pixel's patch: false = some rejection test of Functions.cuh:72-86 holds at all four corners by the margin,
+// hence for every camera ray of the pixel (see above).  s = camera - v0, q = cross(s, e0); dmax = 1e-4 * the largest |corner|_1.
+__device__ __forceinline__ bool corners_can_hit(const Vec3* corner, float dmax, Vec3 e0, Vec3 e1, Vec3 s, Vec3 q) {
+	float ne0 = l1norm(e0), ne1 = l1norm(e1), ns = l1norm(s), nq = l1norm(q);
+	float m_det = dmax * ne0 * ne1, m_a = dmax * ns * ne1, m_b = dmax * nq;
+	float m_u1 = m_a + m_det, m_uv1 = m_a + m_b + m_det;
+	bool det_neg = true, a_neg = true, b_neg = true, u_gt1 = true, uv_gt1 = true;
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		Vec3 h = cross3(corner[c], e1);
+		float det = dot3(e0, h), a = dot3(s, h), b = dot3(corner[c], q);
+		det_neg = det_neg && det < -m_det;
+		a_neg = a_neg && a < -m_a;
+		b_neg = b_neg && b < -m_b;
+		u_gt1 = u_gt1 && a - det > m_u1;
+		uv_gt1 = uv_gt1 && a + b - det > m_uv1;
+	}
+	return !(det_neg || a_neg || b_neg || u_gt1 || uv_gt1);
+}
+
 __device__ __forceinline__ unsigned long long primary_need_mask(const FrameDev& f, uint32_t px, uint32_t py, bool active,
                                                                 const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t n_tris) {
 	if (n_tris > 64u) return ~0ull;
@@ -909,22 +945,8 @@ __device__ __forceinline__ unsigned long long primary_need_mask(const FrameDev& 
 		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
 		float4 pa = prim[2 * k + 0], pb = prim[2 * k + 1];
 		Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x }, s{ pa.x, pa.y, pa.z }, q{ pb.x, pb.y, pb.z };
-		float ne0 = l1norm(e0), ne1 = l1norm(e1), ns = l1norm(s), nq = l1norm(q);
-		float m_det = dmax * ne0 * ne1, m_a = dmax * ns * ne1, m_b = dmax * nq;
-		float m_u1 = m_a + m_det, m_uv1 = m_a + m_b + m_det;
-		bool det_neg = true, a_neg = true, b_neg = true, u_gt1 = true, uv_gt1 = true;
 		const Vec3 corner[4] = { c0, c1, c2, c3 };
-#pragma unroll
-		for (int c = 0; c < 4; c++) {
-			Vec3 h = cross3(corner[c], e1);
-			float det = dot3(e0, h), a = dot3(s, h), b = dot3(corner[c], q);
-			det_neg = det_neg && det < -m_det;
-			a_neg = a_neg && a < -m_a;
-			b_neg = b_neg && b < -m_b;
-			u_gt1 = u_gt1 && a - det > m_u1;
-			uv_gt1 = uv_gt1 && a + b - det > m_uv1;
-		}
-		bool can_hit = active && !(det_neg || a_neg || b_neg || u_gt1 || uv_gt1);
+		bool can_hit = active && corners_can_hit(corner, dmax, e0, e1, s, q);
 		if (__ballot(can_hit) != 0ull) need |= 1ull << k;
 	}
 	return need;
@@ -952,7 +974,9 @@ __device__ __forceinline__ float4 running_mean(float4 color, float4 prev, uint32
 // and t |d'| cannot exceed the reach of the scene from the camera: R_c passes within delta_k + extra of k, extra = chord * reach /
 // |d'|.  The walk of R_c with every box grown by `extra` more, no pruning by distance (best_t = FLT_MAX), and every class taken
 // chord / |d| closer to grazing (rho is 1-Lipschitz in the unit direction; Dunkl-Williams for the normalisation) therefore reaches
-// the leaf of k.  A pixel whose walk finds more than PT_PRIMARY_LIST_LEAVES leaves is marked and keeps walking per ray.
+// the leaf of k.  Of a leaf's triangles the list keeps those that pass corners_can_hit -- the rejection tests of the fp32 routine
+// itself, linear in the direction, at the patch's four corners: a second, independent superset -- one entry per triangle.  A pixel
+// whose walk finds more than PT_PRIMARY_LIST_LEAVES of them is marked and keeps walking per ray.
 constexpr uint32_t kPrimaryListCap = PT_PRIMARY_LIST_LEAVES;
 constexpr uint32_t kPrimaryListWalk = 0xFFFFFFFFu;          // lists[pixel]: this pixel's camera rays walk the tree
 
@@ -994,9 +1018,17 @@ __device__ __forceinline__ void bvh_collect_pixel(const BvhView& bv, const Frame
 	// a cone too wide for the bound to mean anything (a camera inside out, a 2 x 2 image): the pixel walks per ray
 	const bool ok = active && pc.dmin > 0.05f && pc.chord < 0.05f;
 	const float reach = bv.s_bound + (bv.kappa_root * bv.s_bound + bv.slack);          // |origin - hit| <= |origin - centre| + radius + delta
-	BvhCollect col{ lists + (size_t)pixel_count + li, pixel_count, kPrimaryListCap, 0u,
-	                ok ? 1.01f * pc.chord * reach / pc.dmin + 1e-6f : 0.0f, ok ? 1.01f * pc.chord / pc.dmin : 0.0f };
 	const Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
+	BvhCollect col{ lists + (size_t)pixel_count + li, pixel_count, kPrimaryListCap, 0u,
+	                ok ? 1.01f * pc.chord * reach / pc.dmin + 1e-6f : 0.0f, ok ? 1.01f * pc.chord / pc.dmin : 0.0f, o, {}, 0.0f };
+	{
+		// the patch's corners as primary_need_mask takes them: unnormalised screen points (the tests are linear in the direction)
+		const float x0 = (float)px / (float)f.width, x1 = ((float)px + 1.0f) / (float)f.width;
+		const float y0 = (float)py / (float)f.height, y1 = ((float)py + 1.0f) / (float)f.height;
+		col.corner[0] = screen_point(f, x0, y0); col.corner[1] = screen_point(f, x1, y0);
+		col.corner[2] = screen_point(f, x0, y1); col.corner[3] = screen_point(f, x1, y1);
+		col.dmax = 1e-4f * fmaxf(fmaxf(l1norm(col.corner[0]), l1norm(col.corner[1])), fmaxf(l1norm(col.corner[2]), l1norm(col.corner[3])));
+	}
 	float best = FLT_MAX;
 	uint32_t tri = kNoHit;
 	BvhRay r{};
@@ -1012,7 +1044,7 @@ __device__ __forceinline__ void bvh_collect_pixel(const BvhView& bv, const Frame
 }
 
 // The camera ray of pixel li against its listed leaves: the same tests, ranked the same way, as the walk would have made among
-// (at least) the leaves it would have reached.  False: the pixel has no list (kPrimaryListWalk), walk.
+// (at least) the triangles it could have accepted.  False: the pixel has no list (kPrimaryListWalk), walk.
 __device__ __forceinline__ bool bvh_list_intersect(const BvhView& bv, const uint32_t* __restrict__ lists, uint32_t pixel_count, uint32_t li,
                                                    Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri) {
 	const uint32_t n = lists[li];

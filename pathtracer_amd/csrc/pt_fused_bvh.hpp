@@ -22,6 +22,12 @@ namespace ptd {
 #define PT_FUSED_SERVICE 32
 #endif
 
+// service trips in a row while camera rays keep finishing on their pixels' leaf lists (fused_bvh_block)
+#ifndef PT_FUSED_LIST_TRIPS
+#define PT_FUSED_LIST_TRIPS 3
+#endif
+constexpr uint32_t kFusedListTrips = PT_FUSED_LIST_TRIPS;
+
 struct FusedBvhCtx {
 	FrameDev f;
 	BvhView bv;
@@ -88,7 +94,12 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 		const bool any_walking = __any(walking);
 		if (n_waiting >= (uint32_t)PT_FUSED_SERVICE || (!any_walking && n_waiting != 0u)) {
 			bool fresh = false;          // the lane has a new ray to set up
-			if (waiting && has_ray) {
+			// With camera-ray leaf lists a camera ray is FINISHED where it is made (no walk), so the lane that made it is due for a shade
+			// again at once: the service goes round -- shade, next ray, and if that one is finished too, shade again -- until every lane
+			// it serves holds a ray that walks or has nothing left, a few trips at most (a pixel whose camera rays all end where they hit
+			// would otherwise hold the walkers for its whole sample count: it waits for the next service like everybody else)
+			for (uint32_t trip = 0;; trip++) {
+			if (waiting && has_ray && !fresh) {
 				// Intersect (kernels.cu:71-94) for the hit `tri` of bounce b
 				float4 frame = float4{ 0.0f, 0.0f, 0.0f, 1.0f };
 				bool alive = false;
@@ -171,6 +182,8 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
 					tri = kNoHit;
 					if (bvh_list_intersect(c.bv, f.primary_lists, f.pixel_count, li, o, d, best, tri)) { n_rays++; fresh = false; }
 				}
+			}
+			if (f.primary_lists == nullptr || trip >= kFusedListTrips || !__any(waiting && has_ray && !fresh)) break;
 			}
 			if (fresh) {
 				n_rays++;
