@@ -377,79 +377,91 @@ __global__ __launch_bounds__(kBlock, 8) void k_primary_lists(FrameDev f, const u
 // path is written out as a queue entry in the full format of a later bounce (origin, direction, best_t = FLT_MAX, throughput 1) into
 // the block's own slots of queue 0, counted in over_count[b], and the ordinary extend and shade stages finish those few behind
 // this kernel (launch_shade append) -- no traversal code, no stack here.
-constexpr uint32_t kCameraMaxSamples = 64;           // sample matrices staged in LDS (8 KiB); passes of more samples take the staged stages
+// Ownership is like the one-launch pass's (pt_wavefront.hpp, bounces_block): a block owns pixels -- 64-pixel tiles, dealt to its waves --
+// with ALL samples of the pass, a lane keeps its pixel and walks the samples in order -- pixel coordinates divided out once per pixel,
+// the strided stream of sample s+1 ONE byte-table jump (step^stride, 4 LDS lookups) from that of sample s instead of a 32-column
+// matrix product per path, the pixel's list read once into L1.  Measured against a path-per-lane form over the identity queue (one
+// matrix product and three integer divisions per path): 688 -> see DESIGN 4.4 us per 16-sample pass at 10 092 triangles.
+// The queues' slots are still the block's own ((r G + b) 256 + t), so the stages behind need not know; a block holds up to
+// ceil(chunks / G) * n_samples rows (queue_capacity covers it).
 template <bool STRIDED>
-__global__ __launch_bounds__(kBlock, 8) void k_camera_lists(FrameDev f, const uint32_t* __restrict__ smat, uint32_t n_samples, const uint32_t* __restrict__ rng_in,
+__global__ __launch_bounds__(kBlock, 8) void k_camera_lists(FrameDev f, JumpMat pass_first, JumpMat per_sample, uint32_t n_samples, const uint32_t* __restrict__ rng_in,
                                                             const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats, uint32_t last_bounce,
-                                                            const uint32_t* __restrict__ count_ptr, uint32_t capacity,
+                                                            uint32_t capacity,
                                                             float4* __restrict__ wa, float4* __restrict__ wb, float4* __restrict__ wc, uint32_t* __restrict__ wpid,
                                                             uint32_t* __restrict__ over_count,
                                                             float4* __restrict__ oa, float4* __restrict__ ob, float4* __restrict__ oc, uint32_t* __restrict__ opid,
-                                                            uint32_t* __restrict__ count_out,
+                                                            uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out,
                                                             float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out) {
 	__shared__ uint32_t s_jump[1024];
-	__shared__ uint32_t s_mat[STRIDED ? 32 * kCameraMaxSamples : 1];
-	__shared__ uint32_t s_out, s_traced, s_over;
+	__shared__ uint32_t s_stride[STRIDED ? 1024 : 1];
+	__shared__ uint32_t s_first[STRIDED ? 32 : 1], s_per[STRIDED ? 32 : 1];
+	__shared__ uint32_t s_out, s_traced, s_over, s_owned;
 	if (!scene_guard(scene, n_tris, true)) return;
 	stage_jump31(s_jump);
-	if (STRIDED) for (uint32_t t = threadIdx.x; t < 32u * n_samples; t += kBlock) s_mat[t] = smat[t];
-	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; s_over = 0; }
+	if (STRIDED) {
+		if (threadIdx.x < 32) { s_first[threadIdx.x] = pass_first.cols[threadIdx.x]; s_per[threadIdx.x] = per_sample.cols[threadIdx.x]; }
+		__syncthreads();
+		build_stride_table(s_per, s_stride);
+	}
+	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; s_over = 0; s_owned = 0; }
 	const BvhView bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
 	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
 	const float4* mats = tris + (size_t)n_tris * 4;
 	__syncthreads();
 	ShadeCtx c{ f, tris, mats, s_jump, n_tris, bv.det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
 	const uint32_t G = gridDim.x, lane = threadIdx.x & 63u;
-	const uint32_t count = count_ptr[blockIdx.x];
 	const bool extended = f.shading == PT_SHADING_EXTENDED;
 	const Vec3 o{ f.origin.x, f.origin.y, f.origin.z };
-	const float inv_pixels = 1.0f / (float)f.pixel_count;
-	for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
-		const uint32_t q = queue_slot(j0, G) + threadIdx.x;          // == the path id
-		const bool active = j0 + threadIdx.x < count && q < capacity;
-		PathNext r;
-		r.pid = q;
-		bool over = false;
-		Vec3 d{ 0, 0, 0 };
-		uint32_t rng = 0;
-		if (active) {
-			// sample and local pixel of path q = s * pixel_count + li: a float estimate of the quotient (s < 2^16, so it is off by one at most) and one correction either way
-			uint32_t s = STRIDED ? (uint32_t)((float)q * inv_pixels) : 0u;
-			int32_t rem = (int32_t)(q - s * f.pixel_count);
-			if (STRIDED) {
-				if (rem < 0) { s--; rem += (int32_t)f.pixel_count; }
-				else if ((uint32_t)rem >= f.pixel_count) { s++; rem -= (int32_t)f.pixel_count; }
+	uint32_t owned = 0;                                              // wave-uniform: pixels of this wave's tiles
+	// (64-pixel tiles, wave by wave: wave w of block b takes the tiles b + w G, b + w G + 4 G, ... -- a block's queue then holds
+	// paths from sixteen places of the image instead of four whole chunks, and the persistent stages behind, whose time is their
+	// slowest block's, stay balanced: with 256-pixel chunks the extend and the tail lost more than this kernel gained)
+	for (uint32_t li0 = (blockIdx.x + (threadIdx.x >> 6) * G) * 64u; li0 < f.pixel_count; li0 += G * kBlock) {
+		const uint32_t li = li0 + lane;
+		const bool active = li < f.pixel_count;
+		owned += min(64u, f.pixel_count - li0);
+		const uint32_t i = f.pixel_first + (active ? li : 0u);
+		const uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
+		uint32_t r0 = active ? rng_in[li] : 0u;
+		if (STRIDED) r0 = mat_apply_lds(s_first, r0);                  // the start of the pass's first sample (once per pixel)
+		for (uint32_t smp = 0; smp < n_samples; smp++) {
+			if (STRIDED && smp) r0 = byte_jump(s_stride, r0);
+			PathNext r;
+			r.pid = smp * f.pixel_count + li;
+			bool over = false;
+			Vec3 d{ 0, 0, 0 };
+			uint32_t rng = r0;                                           // r0 stays the start of this sample's stream
+			if (active) {
+				d = primary_direction(f, px, py, rng);
+				float best = FLT_MAX;
+				uint32_t tri = kNoHit;
+				over = !bvh_list_intersect(bv, f.primary_lists, f.pixel_count, li, o, d, best, tri);
+				if (!over) shade_lane<true, false, true, false>(c, extended, last_bounce, r.pid, uint2{ __float_as_uint(best), tri },
+				                                                float4{ d.x, d.y, d.z, __uint_as_float(rng) }, nullptr, nullptr, nullptr, r);
 			}
-			const uint32_t li = (uint32_t)rem;
-			const uint32_t i = f.pixel_first + li;
-			rng = rng_in[li];
-			if (STRIDED) rng = mat_apply_lds(s_mat + 32u * s, rng);
-			d = primary_direction(f, i % (uint32_t)f.width, i / (uint32_t)f.width, rng);
-			float best = FLT_MAX;
-			uint32_t tri = kNoHit;
-			over = !bvh_list_intersect(bv, f.primary_lists, f.pixel_count, li, o, d, best, tri);
-			if (!over) shade_lane<true, false, true, false>(c, extended, last_bounce, q, uint2{ __float_as_uint(best), tri },
-			                                                float4{ d.x, d.y, d.z, __uint_as_float(rng) }, nullptr, nullptr, nullptr, r);
-		}
-		queue_push<false, false>(c, last_bounce, r, oa, ob, oc, opid, nullptr);
-		// the paths that need a walk: compacted like the others, into the block's own slots of queue 0
-		const unsigned long long over_mask = __ballot(over);
-		if (over_mask != 0ull) {
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(&s_over, (uint32_t)__popcll(over_mask));
-			base = __shfl(base, 0, 64);
-			if (over) {
-				const uint32_t j = base + (uint32_t)__popcll(over_mask & ((1ull << lane) - 1ull));
-				const uint32_t pos = ((j / kQueueBlock) * G + blockIdx.x) * kQueueBlock + (j % kQueueBlock);
-				wa[pos] = float4{ o.x, o.y, o.z, d.x };
-				wb[pos] = float4{ d.y, d.z, FLT_MAX, __uint_as_float(rng) };
-				wc[pos] = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
-				wpid[pos] = q;
+			queue_push<false, false>(c, last_bounce, r, oa, ob, oc, opid, nullptr);
+			// the paths that need a walk: compacted like the others, into the block's own slots of queue 0
+			const unsigned long long over_mask = __ballot(over);
+			if (over_mask != 0ull) {
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(&s_over, (uint32_t)__popcll(over_mask));
+				base = __shfl(base, 0, 64);
+				if (over) {
+					const uint32_t j = base + (uint32_t)__popcll(over_mask & ((1ull << lane) - 1ull));
+					const uint32_t pos = ((j / kQueueBlock) * G + blockIdx.x) * kQueueBlock + (j % kQueueBlock);
+					wa[pos] = float4{ o.x, o.y, o.z, d.x };
+					wb[pos] = float4{ d.y, d.z, FLT_MAX, __uint_as_float(rng) };
+					wc[pos] = float4{ 1.0f, 1.0f, 1.0f, 1.0f };
+					wpid[pos] = r.pid;
+				}
 			}
 		}
 	}
+	if (lane == 0u && owned != 0u) atomicAdd(&s_owned, owned);
 	__syncthreads();
-	if (threadIdx.x == 0) { count_out[blockIdx.x] = s_out; over_count[blockIdx.x] = s_over; }
+	// counts row 0 = the camera rays of this block (the statistics' bounce-0 rays), row 1 = the paths it queued
+	if (threadIdx.x == 0) { count_in[blockIdx.x] = s_owned * n_samples; count_out[blockIdx.x] = s_out; over_count[blockIdx.x] = s_over; }
 }
 
 template <bool FIRST, bool SCENE_LDS, bool EXTEND>
@@ -894,10 +906,21 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Queue capacity of a pass.  The one-launch pass (k_bounces) gives block b the pixel chunks {k : k % G == b} with all
 // samples, G = grid_for_pass(pixel_count), so every block needs ceil(chunks/G) * samples_per_pass rows of 256 slots: the
 // path count rounded up to whole rows for every block (at most one chunk-row of padding per block).
-size_t queue_capacity(uint32_t pixel_count, uint32_t samples_per_pass) {
+// The staged pass of a BVH scene with camera-ray leaf lists (k_camera_lists) deals the pixel chunks out the same way over ITS grid,
+// G' = grid_for_chunks(pixel_count) (at most 8 blocks per CU): the capacity covers both.
+int grid_for_chunks(uint32_t pixel_count) { return grid_for((((size_t)pixel_count + kBlock - 1) / kBlock) * kBlock); }
+size_t owned_slots(uint32_t pixel_count, uint32_t samples_per_pass, size_t G) {
 	size_t chunks = ((size_t)pixel_count + kBlock - 1) / kBlock;
-	size_t G = (size_t)grid_for_pass(pixel_count);
 	return G * ((chunks + G - 1) / G) * samples_per_pass * kBlock;
+}
+// ... k_camera_lists deals 64-pixel tiles to the 4 G waves: a block owns at most 4 ceil(tiles / 4 G) of them
+size_t owned_slots_tiles(uint32_t pixel_count, uint32_t samples_per_pass, size_t G) {
+	size_t tiles = ((size_t)pixel_count + 63) / 64;
+	return G * ((tiles + 4 * G - 1) / (4 * G)) * samples_per_pass * kBlock;
+}
+size_t queue_capacity(uint32_t pixel_count, uint32_t samples_per_pass) {
+	return std::max(owned_slots(pixel_count, samples_per_pass, (size_t)grid_for_pass(pixel_count)),
+	                owned_slots_tiles(pixel_count, samples_per_pass, (size_t)grid_for_chunks(pixel_count)));
 }
 
 size_t carve(Workspace* w, unsigned char* base, uint32_t pixel_count, uint32_t samples_per_pass) {
@@ -931,9 +954,10 @@ SceneInfo scene_info(const pt_frame* f, uint32_t n_tris, uint32_t n_mats) { retu
 size_t bounces_lds_bytes(const SceneInfo& s) { return (size_t)s.n_tris * (sizeof(TriRec) + sizeof(PrimRec)) + (size_t)s.n_mats * sizeof(MatRec); }
 constexpr size_t kBouncesLdsBudget = 160u * 1024u - 9u * 1024u;
 
+// blocks: the queue blocks G of the pass when they do not follow from the capacity (0: grid_for(capacity), the stage API's rule)
 void launch_extend(const FrameDev& f, uint32_t bounce, const void* scene_blob, const SceneInfo& si, const float4* qa, const float4* qb,
-                   const uint32_t* counts, uint32_t capacity, uint2* hit, hipStream_t s) {
-	dim3 grid(grid_for(capacity)), block(kBlock);
+                   const uint32_t* counts, uint32_t capacity, uint2* hit, hipStream_t s, uint32_t blocks = 0) {
+	dim3 grid(blocks ? (int)blocks : grid_for(capacity)), block(kBlock);
 	const unsigned char* sc = (const unsigned char*)scene_blob;
 	bool bvh = scene_has_bvh(si);
 	guard_ready();
@@ -1258,7 +1282,7 @@ int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob
 static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneInfo& si, uint32_t bounce,
                         pt_queue in, const void* hit, const uint32_t* count_in, uint32_t capacity,
                         pt_queue out, void* hit_out, uint32_t* count_out, void* radiance, void* lit, uint32_t* rng, hipStream_t s,
-                        bool append = false, bool as_later_bounce = false) {
+                        bool append = false, bool as_later_bounce = false, uint32_t blocks = 0) {
 	// append / as_later_bounce: the camera rays k_camera_lists could not finish (their pixels' lists overflowed) come as a queue in
 	// the full format of a later bounce, are shaded as bounce `bounce` (0) and join the paths that kernel already queued
 	uint32_t last = (bounce + 1 >= f.depth) ? 1u : 0u;
@@ -1266,7 +1290,7 @@ static int launch_shade(const FrameDev& f, const void* scene_blob, const SceneIn
 	bool extend = hit_out != nullptr;
 	if (extend && !lds) return fail(PT_ERR_INVALID, "shade: the fused extend needs a scene that fits LDS (<= 1536 triangles, <= 256 materials)");
 	size_t lds_bytes = shade_lds_bytes(si);
-	dim3 grid(grid_for(capacity)), block(kBlock);
+	dim3 grid(blocks ? (int)blocks : grid_for(capacity)), block(kBlock);
 	guard_ready();
 #define PT_SHADE(FIRST, LDS, EXT) hipLaunchKernelGGL((k_shade<FIRST, LDS, EXT>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, last, si.bvh ? 1u : 0u, \
 	(const float4*)in.a, (const float4*)in.b, (const float4*)in.c, (const uint32_t*)in.pid, (const uint2*)hit, count_in, capacity, \
@@ -1342,9 +1366,14 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 	const bool fuse = shade_scene_in_lds(si) && !scene_has_bvh(si) && bounces_lds_bytes(si) <= kBouncesLdsBudget;
 	if (!fuse) per_launch = samples_per_pass;
 	per_launch = std::min(per_launch, 0x7FFFFFFFu);          // bounces_block<true> keeps a flag in the sample index's top bit
+	// BVH scenes with camera-ray leaf lists: the camera rays are made, intersected, shaded and queued in one launch (k_camera_lists),
+	// whose blocks own pixel chunks -- the queue geometry of the whole pass follows it
+	const bool camera_fused = !fuse && scene_has_bvh(si) && f.primary_lists != nullptr && !std::getenv("PT_CAMERA_STAGED");
 	// queue blocks: fixed for every stage of every pass
-	const uint32_t G = (uint32_t)(fuse ? grid_for_pass(frame->pixel_count) : grid_for(paths_cap));
+	const uint32_t G = (uint32_t)(fuse ? grid_for_pass(frame->pixel_count) : camera_fused ? grid_for_chunks(frame->pixel_count) : grid_for(paths_cap));
 	const uint32_t slots = (uint32_t)queue_capacity(frame->pixel_count, samples_per_pass);
+	// what the stages take as the queues' capacity: the identity queue's path count, or every slot a chunk-owning block can reach
+	const uint32_t stage_cap = camera_fused ? (uint32_t)owned_slots_tiles(frame->pixel_count, samples_per_pass, G) : (uint32_t)paths_cap;
 	if (fuse && stats && (uint64_t)(slots / G / samples_per_pass) * n_samples > 0xFFFFFFFFull)
 		return fail(PT_ERR_LIMIT, "render_wavefront: more samples in one call than the 32-bit ray counters of a block hold");
 
@@ -1374,25 +1403,29 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 			bool last_pass = done + per_launch >= n_samples;
 			if (stats && last_pass) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.ray_counts, G, frame->depth, (unsigned long long*)stats);
 		} else {
-			hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
 			// camera rays through their pixels' leaf lists: made, intersected, shaded and queued in one launch (k_camera_lists)
-			const bool camera_fused = scene_has_bvh(si) && f.primary_lists != nullptr && ns <= kCameraMaxSamples && !std::getenv("PT_CAMERA_STAGED");
-			if (!camera_fused) { if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc; }
-			else {
+			if (!camera_fused) {
+				hipLaunchKernelGGL(k_set_count, dim3((G + 63) / 64), dim3(64), 0, s, w.counts, G, paths);
+				if (int rc = launch_generate(frame, frame_first + done, ns, rng, w.smat, scene_blob, si.n_tris, w.b[0], nullptr, s)) return rc;
+			} else {
 				uint32_t* over = w.counts + (size_t)(PT_MAX_DEPTH + 1) * G;          // a spare row of the counters: paths whose pixels have no list
-				if (!sequential) hipLaunchKernelGGL(k_sample_matrices, dim3(ns), dim3(32), 0, s, frame_first + done, frame->stride, w.smat);
+				JumpMat first{}, per{};
+				if (!sequential) {
+					host_jump_matrix((uint64_t)(frame_first + done) * frame->stride, first.cols);
+					host_jump_matrix(frame->stride, per.cols);
+				}
 				const uint32_t last0 = frame->depth <= 1u ? 1u : 0u;
-#define PT_CAM(STR) hipLaunchKernelGGL(k_camera_lists<STR>, dim3(G), dim3(kBlock), 0, s, f, (const uint32_t*)w.smat, ns, (const uint32_t*)rng, (const unsigned char*)scene_blob, \
-				si.n_tris, si.n_mats, last0, (const uint32_t*)w.counts, (uint32_t)paths_cap, w.a[0], w.b[0], w.c[0], w.pid[0], over, \
-				w.a[1], w.b[1], w.c[1], w.pid[1], w.counts + G, w.radiance, w.lit, sequential ? rng : nullptr)
+#define PT_CAM(STR) hipLaunchKernelGGL(k_camera_lists<STR>, dim3(G), dim3(kBlock), 0, s, f, first, per, ns, (const uint32_t*)rng, (const unsigned char*)scene_blob, \
+				si.n_tris, si.n_mats, last0, stage_cap, w.a[0], w.b[0], w.c[0], w.pid[0], over, \
+				w.a[1], w.b[1], w.c[1], w.pid[1], w.counts, w.counts + G, w.radiance, w.lit, sequential ? rng : nullptr)
 				if (sequential) PT_CAM(false); else PT_CAM(true);
 #undef PT_CAM
 				FrameDev fw = f;
 				fw.primary_lists = nullptr;
-				launch_extend(fw, 1, scene_blob, si, w.a[0], w.b[0], over, (uint32_t)paths_cap, w.hit[0], s);       // (bounce 1's form: rays with an origin of their own)
+				launch_extend(fw, 1, scene_blob, si, w.a[0], w.b[0], over, stage_cap, w.hit[0], s, G);       // (bounce 1's form: rays with an origin of their own)
 				pt_queue qi{ w.a[0], w.b[0], w.c[0], w.pid[0] }, qo{ w.a[1], w.b[1], w.c[1], w.pid[1] };
-				if (int rc = launch_shade(f, scene_blob, si, 0, qi, w.hit[0], over, (uint32_t)paths_cap, qo, nullptr, w.counts + G, w.radiance, w.lit,
-				                          sequential ? rng : nullptr, s, true, true)) return rc;
+				if (int rc = launch_shade(f, scene_blob, si, 0, qi, w.hit[0], over, stage_cap, qo, nullptr, w.counts + G, w.radiance, w.lit,
+				                          sequential ? rng : nullptr, s, true, true, G)) return rc;
 			}
 			// BVH scenes: the first bounces staged (camera rays, and the bulk of the bounced ones, each in an extend of its own at full
 			// occupancy, each shade a streaming pass), the RAYS of bounce kTailEntryBounce and everything after them in one persistent launch
@@ -1401,23 +1434,23 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 			if (tail_from >= 1u && tail_from < frame->depth && tail_from < 0xFFFFFFFFu) {
 				for (uint32_t b = camera_fused ? 1u : 0u; b < tail_from; b++) {
 					int in = b & 1, out = in ^ 1;
-					launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
+					launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, stage_cap, w.hit[in], s, G);
 					pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
-					if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
-					                          nullptr, w.counts + (size_t)(b + 1) * G, w.radiance, w.lit, sequential ? rng : nullptr, s)) return rc;
+					if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, stage_cap, qo,
+					                          nullptr, w.counts + (size_t)(b + 1) * G, w.radiance, w.lit, sequential ? rng : nullptr, s, false, false, G)) return rc;
 				}
 				int in = tail_from & 1;
 				size_t lds = (size_t)bvh_stack_depth(si.n_tris) * kBlock * sizeof(uint32_t);
 				hipLaunchKernelGGL(k_bounce_tail, dim3(G), dim3(kBlock), lds, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, tail_from,
 				                   (const float4*)w.a[in], (const float4*)w.b[in], (const float4*)w.c[in], (const uint32_t*)w.pid[in],
-				                   w.counts, (uint32_t)paths_cap, w.radiance, w.lit, sequential ? rng : nullptr);
+				                   w.counts, stage_cap, w.radiance, w.lit, sequential ? rng : nullptr);
 			} else
 			for (uint32_t b = camera_fused ? 1u : 0u; b < frame->depth; b++) {
 				int in = b & 1, out = in ^ 1;
-				launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, w.hit[in], s);
+				launch_extend(f, b, scene_blob, si, w.a[in], w.b[in], w.counts + (size_t)b * G, stage_cap, w.hit[in], s, G);
 				pt_queue qi{ w.a[in], w.b[in], w.c[in], w.pid[in] }, qo{ w.a[out], w.b[out], w.c[out], w.pid[out] };
-				if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, (uint32_t)paths_cap, qo,
-				                          nullptr, w.counts + (size_t)(b + 1) * G, w.radiance, w.lit, sequential ? rng : nullptr, s)) return rc;
+				if (int rc = launch_shade(f, scene_blob, si, b, qi, w.hit[in], w.counts + (size_t)b * G, stage_cap, qo,
+				                          nullptr, w.counts + (size_t)(b + 1) * G, w.radiance, w.lit, sequential ? rng : nullptr, s, false, false, G)) return rc;
 			}
 			hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
 			                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
