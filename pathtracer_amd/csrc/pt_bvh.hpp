@@ -66,6 +66,26 @@ struct QNode {
 };
 static_assert(sizeof(QNode) == 32, "quantised BVH node is 2 x 16 bytes");
 
+// ---- PT_BVH_WIDE (round 3; default on): four children per node ----
+// The binary tree collapsed pairwise at pack time: a wide node holds the GRANDCHILDREN of a binary node (a child that is a leaf
+// stays as it is), 2..4 children, each a 16-byte half {box, reference} as in QNode -- one 64-byte line per node step, and half as
+// many dependent steps from the root to a leaf (13.2 -> 6.8 node steps per ray at 10 092 triangles).  Its inner depth is
+// ceil(binary depth / 2); a walk defers up to three children per level (ptd::bvh_stack_total: the binary budget's worth of levels in
+// LDS, the rest in private memory).  Empty slots hold kEmptyChild behind an inside-out box.
+#ifndef PT_BVH_WIDE
+#define PT_BVH_WIDE 1
+#endif
+constexpr int32_t kEmptyChild = 0x7FFFFFFD;        // == ptd::kBvhEmpty
+struct Node4 {
+	float lo[4][3], hi[4][3];
+	int32_t child[4];
+	uint32_t n;
+};
+struct QNode4 {
+	struct Half { uint16_t box[3][2]; int32_t child; } c[4];
+};
+static_assert(sizeof(QNode4) == 64, "wide quantised BVH node is 4 x 16 bytes");
+
 // 64 bytes: what the leaf test needs, in BVH order.  {v0.xyz, e0.x} {e0.yz, e1.xy} {e1.z, orig index bits, 0, 0} {pad}
 struct LeafTri { float f[16]; };
 
@@ -118,6 +138,7 @@ static_assert(sizeof(ClassBlock) == 320, "class block is 320 bytes");
 struct Built {
 	ClassBlock classes{};
 	std::vector<Node> nodes;
+	std::vector<Node4> nodes4;                     // PT_BVH_WIDE: the same trees collapsed (classes.second_root then indexes THIS array)
 	std::vector<LeafTri> tris;
 	float center[3] = { 0, 0, 0 };
 	float radius = 0.0f;
@@ -223,7 +244,62 @@ inline std::vector<QNode> quantize(const std::vector<Node>& nodes, const float g
 	return out;
 }
 
+// binary node `root2` and everything below it, appended to `out`; returns the wide node's index
+inline int32_t collapse(const std::vector<Node>& nodes, int32_t root2, std::vector<Node4>& out) {
+	const int32_t me = (int32_t)out.size();
+	out.emplace_back();
+	Node4 w{};
+	auto add = [&](const float* lo, const float* hi, int32_t ref) {
+		for (int k = 0; k < 3; k++) { w.lo[w.n][k] = lo[k]; w.hi[w.n][k] = hi[k]; }
+		w.child[w.n++] = ref;
+	};
+	const Node& b = nodes[(size_t)root2];
+	const int32_t refs[2] = { b.child0, b.child1 };
+	for (int side = 0; side < 2; side++) {
+		if (refs[side] >= 0) {
+			const Node& c = nodes[(size_t)refs[side]];
+			add(c.lo0, c.hi0, c.child0);
+			add(c.lo1, c.hi1, c.child1);
+		} else add(side ? b.lo1 : b.lo0, side ? b.hi1 : b.hi0, refs[side]);
+	}
+	for (uint32_t k = 0; k < w.n; k++) if (w.child[k] >= 0) w.child[k] = collapse(nodes, w.child[k], out);
+	for (uint32_t k = w.n; k < 4; k++) { for (int a = 0; a < 3; a++) { w.lo[k][a] = 1e30f; w.hi[k][a] = -1e30f; } w.child[k] = kEmptyChild; }
+	out[(size_t)me] = w;
+	return me;
+}
+
+// the most entries a walk of the wide tree can have deferred at once: a node with k children defers up to k - 1 of them
+inline uint32_t stack_need4(const std::vector<Node4>& nodes, uint32_t root = 0) {
+	if (nodes.empty()) return 0;
+	uint32_t worst = 0;
+	std::vector<std::pair<int32_t, uint32_t>> todo{ { (int32_t)root, 0u } };
+	while (!todo.empty()) {
+		auto [i, held] = todo.back();
+		todo.pop_back();
+		const Node4& w = nodes[(size_t)i];
+		const uint32_t here = held + (w.n - 1u);
+		worst = std::max(worst, here);
+		for (uint32_t k = 0; k < w.n; k++) if (w.child[k] >= 0) todo.push_back({ w.child[k], here });
+	}
+	return worst;
+}
+
+inline std::vector<QNode4> quantize4(const std::vector<Node4>& nodes, const float glo[3], float cell);
+
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+inline std::vector<QNode4> quantize4(const std::vector<Node4>& nodes, const float glo[3], float cell) {
+	std::vector<QNode4> out(nodes.size());
+	for (size_t i = 0; i < nodes.size(); i++)
+		for (int c = 0; c < 4; c++) {
+			for (int k = 0; k < 3; k++) {
+				out[i].c[c].box[k][0] = grid_down(nodes[i].lo[c][k], glo[k], cell);
+				out[i].c[c].box[k][1] = grid_up(nodes[i].hi[c][k], glo[k], cell);
+			}
+			out[i].c[c].child = nodes[i].child[c];
+		}
+	return out;
+}
 
 inline void bounds_of(const std::vector<Prim>& p, uint32_t a, uint32_t b, float lo[3], float hi[3], float& kappa) {
 	for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
@@ -376,7 +452,7 @@ inline uint32_t inner_depth(const std::vector<Node>& nodes, uint32_t root = 0) {
 	return deepest;
 }
 
-// stack_depth: ptd::bvh_stack_depth(n_tris), what the traversal's stack holds
+// stack_depth: ptd::bvh_depth_budget(n_tris), the binary levels the traversal's stack is sized for
 inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, uint32_t stack_depth) {
 	Built out;
 	std::vector<Prim> prims(n_tris);
@@ -485,6 +561,14 @@ inline Built build(const pt_vertex* v, const pt_triangle* t, uint32_t n_tris, ui
 		build_tree(0, n_cls);
 		out.classes.second_root = build_tree(n_cls, n_tris);
 	} else build_tree(0, n_tris);
+	if (PT_BVH_WIDE) {
+		collapse(out.nodes, 0, out.nodes4);
+		if (two) {
+			const uint32_t second2 = out.classes.second_root;
+			out.classes.second_root = (uint32_t)out.nodes4.size();
+			collapse(out.nodes, (int32_t)second2, out.nodes4);
+		}
+	}
 	out.classes.first_is_free = n_cls == 0 ? 1u : 0u;
 	out.classes.n_first = two ? n_cls : n_tris;
 	for (uint32_t i = 0; i < n_tris; i++) out.kappa_root = std::max(out.kappa_root, prims[i].kappa == prims[i].kappa ? prims[i].kappa : INFINITY);

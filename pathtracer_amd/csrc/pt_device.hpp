@@ -192,13 +192,33 @@ constexpr uint32_t kBvhMinTris = PT_BVH_DEFAULT_MIN_TRIANGLES;    // the measure
 #endif
 constexpr uint32_t kBvhLeafSize = PT_BVH_LEAF;     // == ptbvh::kLeafSize
 constexpr uint32_t kBvhDepthSlack = 3;     // levels the builder may spend on unbalanced (surface-area) splits, pt_bvh.hpp
-__host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) {
+#ifndef PT_BVH_WIDE
+#define PT_BVH_WIDE 1                      // pt_bvh.hpp: four children per node; 0: the binary tree of rounds 1-2 (kept for same-box A/B runs)
+#endif
+// binary levels the builder may use
+__host__ __device__ inline uint32_t bvh_depth_budget(uint32_t n_tris) {
 	uint32_t d = 0;
 	while (n_tris > kBvhLeafSize) { n_tris = (n_tris + 1u) / 2u; d++; }    // the larger half decides
 	return (d < 1u ? 1u : d) + kBvhDepthSlack;
 }
+// levels of the per-lane stack in LDS (what the launchers size the dynamic LDS from)
+#ifdef PT_BVH_LDS_LEVELS            // tests/host only (bvh_host_check_spill): a few levels, so that every walk runs into the private part
+__host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) { return bvh_depth_budget(n_tris) < PT_BVH_LDS_LEVELS ? bvh_depth_budget(n_tris) : PT_BVH_LDS_LEVELS; }
+#else
+__host__ __device__ inline uint32_t bvh_stack_depth(uint32_t n_tris) { return bvh_depth_budget(n_tris); }
+#endif
+// entries a walk can defer at most.  Wide nodes: ceil(budget / 2) levels, up to three deferred children each, and the two-tree
+// marker; what exceeds the LDS levels goes to kBvhSpill words of private memory (BvhStack) -- the same walk with ALL of these in
+// LDS lost a quarter of the occupancy and 9 % against the binary tree, with the LDS of the binary walk it wins 4..10 %
+__host__ __device__ inline uint32_t bvh_stack_total(uint32_t n_tris) {
+	return PT_BVH_WIDE ? 3u * ((bvh_depth_budget(n_tris) + 1u) / 2u) + 1u : bvh_depth_budget(n_tris);
+}
+#ifndef PT_BVH_SPILL
+#define PT_BVH_SPILL 16
+#endif
+constexpr uint32_t kBvhSpill = PT_BVH_WIDE ? PT_BVH_SPILL : 1u;       // covers bvh_stack_total - bvh_stack_depth up to 2^26 triangles (scene_pack checks)
 
-constexpr uint32_t kBvhNodeBytes = 32;      // pt_bvh.hpp QNode; the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block
+constexpr uint32_t kBvhNodeBytes = PT_BVH_WIDE ? 64 : 32;      // pt_bvh.hpp QNode (QNode4); the blob reserves n_tris of them, then n_tris 64-byte leaf records, then the class block
 constexpr uint32_t kBvhClassBytes = 320;    // pt_bvh.hpp ClassBlock
 constexpr uint32_t kBvhMaxClasses = 8;      // == ptbvh::kMaxClasses
 constexpr float kBvhKappaRho = 16.0f * 5.9604645e-8f / 0.25f;     // == ptbvh::kKappaRho: inflation per unit of S, times the ray's rho (pt_bvh.hpp, normal classes)
@@ -206,7 +226,7 @@ constexpr float kBvhRhoMin = 1e-4f;                              // == ptbvh::kR
 __host__ __device__ inline uint32_t bvh_offset_of(uint32_t n_tris, uint32_t n_mats) {
 	return ((uint32_t)sizeof(SceneHeader) + n_tris * 64u + n_mats * 32u + 63u) & ~63u;
 }
-constexpr uint32_t kSceneMagic = 0x50544857u;  // "PTHW" (T: half nodes {box, child}; U: normal classes as {axis cos h, sin h}; V: + in-plane factors; W: the free triangles in a tree of their own; older blobs are refused)
+constexpr uint32_t kSceneMagic = PT_BVH_WIDE ? 0x50544858u : 0x50544857u;  // "PTHX" / "PTHW" (X: four children per node; T: half nodes {box, child}; U: normal classes as {axis cos h, sin h}; V: + in-plane factors; W: the free triangles in a tree of their own; older blobs are refused)
 
 // The 16-bit grid the BVH's boxes are stored on (pt_bvh.hpp QNode): a cube around the scene's bounding sphere,
 // x = lo + q * cell, q = 0..65535.  Host (scene_pack) and device evaluate this same function.
@@ -313,7 +333,8 @@ struct BvhView {
 	float kappa_root;        // largest kappa in the scene
 	float max_edge;          // longest triangle edge
 	bool det_bounded;        // SceneHeader::flags bit 0
-	int stack_depth;         // bvh_stack_depth(n_tris)
+	int stack_depth;         // bvh_stack_depth(n_tris): levels in LDS
+	int stack_total;         // bvh_stack_total(n_tris): with the private overflow (wide nodes)
 	const float4* classes;   // pt_bvh.hpp NormalClass {axis * cos(h), sin(h)} x n_classes (wave-uniform reads)
 	const float4* in_plane;  // ... and per class how much of an in-plane displacement can point along x, y, z
 	uint32_t n_classes;      // 0: every ray keeps the worst-case inflation (kappa_free == kappa_root then)
@@ -345,6 +366,7 @@ __device__ __forceinline__ BvhView make_bvh_view(const unsigned char* scene, uin
 	v.max_edge = hdr->max_edge;
 	v.det_bounded = (hdr->flags & kSceneDetBounded) != 0;
 	v.stack_depth = (int)bvh_stack_depth(n_tris);
+	v.stack_total = (int)bvh_stack_total(n_tris);
 	v.n_nodes = hdr->n_nodes;
 	v.n_tris = n_tris;
 	const uint32_t* cb = reinterpret_cast<const uint32_t*>(scene + off + (size_t)n_tris * (kBvhNodeBytes + 64u));
@@ -470,6 +492,7 @@ constexpr int32_t kBvhDone = 0x7FFFFFFF;
 // the ray's box constants for the second tree (kappa_free alone) and goes on at its root.  A lane that holds it neither
 // walks nor stands on a leaf.
 constexpr int32_t kBvhSwitch = 0x7FFFFFFE;
+constexpr int32_t kBvhEmpty = 0x7FFFFFFD;     // PT_BVH_WIDE: an unused child slot (== ptbvh::kEmptyChild)
 #ifndef PT_BVH_SPECULATE
 #define PT_BVH_SPECULATE 0     // measured: parking one leaf and walking on costs 25-30 % (10k triangles 2.77 -> 2.02 Grays/s): the parked leaf usually ends the search
 #endif
@@ -481,7 +504,7 @@ constexpr bool kBvhSpeculate = PT_BVH_SPECULATE != 0;
 // one box, wavefront engine, 972 / 10 092 triangles: 2.02 / 3.90 Grays/s without, 2.75 / 4.92 with (16, 4); 8..40 and
 // ratios 2..8 are within 3 % of each other.  0 = wait for all.
 #ifndef PT_BVH_QUORUM
-#define PT_BVH_QUORUM 16
+#define PT_BVH_QUORUM 8        // (wide nodes, round 3: 8 / 16 / 24 -> 16.2 / 16.0 / 15.7 Grays/s at 10 092 triangles, 13.63 / 13.58 / 13.47 at 99 372)
 #endif
 constexpr int kBvhQuorum = PT_BVH_QUORUM;
 #ifndef PT_BVH_RATIO
@@ -573,19 +596,31 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	return r;
 }
 
-// `stack` points at this lane's column of an LDS array laid out [level][256 lanes].
+// A lane's stack of deferred children: its column of an LDS array laid out [level][256 lanes], and -- wide nodes only -- the
+// entries beyond the LDS levels in private memory (dynamically indexed, so it lives in scratch and costs no register).
 // cur: >= 0 inner node; < 0 leaf, ~cur = (first << 3) | (count - 1); kBvhDone: finished.
-__device__ __forceinline__ int32_t bvh_pop(uint32_t* stack, int& sp) {
+struct BvhStack {
+	uint32_t* lds;
+	uint32_t spill[kBvhSpill];
+};
+__device__ __forceinline__ BvhStack bvh_stack_at(uint32_t* s_stack) { BvhStack st; st.lds = s_stack + threadIdx.x; return st; }
+__device__ __forceinline__ void bvh_push(const BvhView& bv, BvhStack& st, int& sp, uint32_t v) {
+	PT_CHECK(sp < bv.stack_total, {});
+	if (!PT_BVH_WIDE || sp < bv.stack_depth) { if (sp < bv.stack_depth) { st.lds[sp * 256] = v; sp++; } }     // (never full: scene_pack checks the tree against it)
+	else if (sp < bv.stack_total && (uint32_t)(sp - bv.stack_depth) < kBvhSpill) { st.spill[sp - bv.stack_depth] = v; sp++; }
+}
+__device__ __forceinline__ int32_t bvh_pop(const BvhView& bv, BvhStack& st, int& sp) {
 	if (sp == 0) return kBvhDone;
 	sp--;
-	return (int32_t)stack[sp * 256];
+	if (PT_BVH_WIDE && sp >= bv.stack_depth) return (int32_t)st.spill[(uint32_t)(sp - bv.stack_depth) < kBvhSpill ? sp - bv.stack_depth : 0];
+	return (int32_t)st.lds[sp * 256];
 }
 
 // A fresh ray: at the root of the tree at node 0, and -- scenes with two trees -- the marker that leads on to the second below
 // everything its walk will stack (the constants the ray starts with are bvh_ray_setup(.., bv.first_free)).
-__device__ __forceinline__ void bvh_start(const BvhView& bv, int32_t& cur, int& sp, uint32_t* stack) {
+__device__ __forceinline__ void bvh_start(const BvhView& bv, int32_t& cur, int& sp, BvhStack& st) {
 	cur = 0; sp = 0;
-	if (bv.second_root != 0u) { stack[0] = (uint32_t)kBvhSwitch; sp = 1; }
+	if (bv.second_root != 0u) { st.lds[0] = (uint32_t)kBvhSwitch; sp = 1; }
 }
 
 // One round of the traversal: walk inner nodes until the lane stands on a leaf (or is done), then test that leaf's
@@ -602,7 +637,7 @@ struct BvhCollect {
 __device__ __forceinline__ bool corners_can_hit(const Vec3* corner, float dmax, Vec3 e0, Vec3 e1, Vec3 s, Vec3 q);
 template <bool COLLECT = false>
 __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
-                                          int32_t& cur, int& sp, uint32_t* stack PT_TIME_PARAM, BvhCollect* col = nullptr) {
+                                          int32_t& cur, int& sp, BvhStack& stack PT_TIME_PARAM, BvhCollect* col = nullptr) {
 	constexpr int32_t kNone = 0;                       // node 0 is the root and never a child, so 0 is free as "no parked leaf"
 	int32_t pend = kNone;
 	PT_TIME_BEGIN();
@@ -616,7 +651,31 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 		}
 		PT_COUNT_WAVE((uint32_t)cur < (uint32_t)kBvhSwitch, 0, 1);
 		if ((uint32_t)cur < (uint32_t)kBvhSwitch) {
-			PT_CHECK((uint32_t)cur < bv.n_nodes && sp >= 0 && sp <= bv.stack_depth, { cur = kBvhDone; sp = 0; continue; });
+			PT_CHECK((uint32_t)cur < bv.n_nodes && sp >= 0 && sp <= bv.stack_total, { cur = kBvhDone; sp = 0; continue; });
+#if PT_BVH_WIDE
+			const uint4* n = bv.nodes + (size_t)cur * 4;
+			const uint4 w0 = n[0], w1 = n[1], w2 = n[2], w3 = n[3];
+			const float thi = best_t + r.dt + 1e-6f * best_t;
+			float tn0, tn1, tn2, tn3;
+			const bool h0 = box_hit(w0.x, w0.y, w0.z, r, thi, tn0);
+			const bool h1 = box_hit(w1.x, w1.y, w1.z, r, thi, tn1);
+			const bool h2 = box_hit(w2.x, w2.y, w2.z, r, thi, tn2) && (int32_t)w2.w != kBvhEmpty;
+			const bool h3 = box_hit(w3.x, w3.y, w3.z, r, thi, tn3) && (int32_t)w3.w != kBvhEmpty;
+			// the nearest child first -- the entry distances are >= -dt, so tn + dt is a non-negative float and its bits order like it,
+			// the slot in the two lowest bits makes the keys distinct -- and the other hits deferred in slot order, unsorted: a network
+			// that sorts all four (64-bit keys, the references riding along) was 3..5 % slower for what the order bought
+			auto key32 = [&](bool h, float tn, uint32_t slot) -> uint32_t { return h ? (__float_as_uint(tn + r.dt) & ~3u) | slot : 0xFFFFFFFFu; };
+			const uint32_t q0 = key32(h0, tn0, 0u), q1 = key32(h1, tn1, 1u), q2 = key32(h2, tn2, 2u), q3 = key32(h3, tn3, 3u);
+			const uint32_t qm = min(min(q0, q1), min(q2, q3));
+			if (qm == 0xFFFFFFFFu) cur = bvh_pop(bv, stack, sp);
+			else {
+				if (h3 && q3 != qm) bvh_push(bv, stack, sp, w3.w);
+				if (h2 && q2 != qm) bvh_push(bv, stack, sp, w2.w);
+				if (h1 && q1 != qm) bvh_push(bv, stack, sp, w1.w);
+				if (h0 && q0 != qm) bvh_push(bv, stack, sp, w0.w);
+				cur = (int32_t)(qm == q0 ? w0.w : qm == q1 ? w1.w : qm == q2 ? w2.w : w3.w);
+			}
+#else
 			const uint4* n = bv.nodes + (size_t)cur * 2;
 			uint4 w0 = n[0], w1 = n[1];
 #ifdef PT_EXP_EXTRA_LOAD
@@ -632,15 +691,15 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 			bool h1 = box_hit(w1.x, w1.y, w1.z, r, thi, tn1);
 			if (h0 && h1) {
 				bool first0 = tn0 <= tn1;
-				PT_CHECK(sp < bv.stack_depth, {});
-				if (sp < bv.stack_depth) { stack[sp * 256] = (uint32_t)(first0 ? c1 : c0); sp++; }     // never false: see bvh_stack_depth
+				bvh_push(bv, stack, sp, (uint32_t)(first0 ? c1 : c0));
 				cur = first0 ? c0 : c1;
 			} else if (h0) cur = c0;
 			else if (h1) cur = c1;
-			else cur = bvh_pop(stack, sp);
+			else cur = bvh_pop(bv, stack, sp);
+#endif
 		} else if (kBvhSpeculate && cur < 0 && pend == kNone) {
 			pend = cur;
-			cur = bvh_pop(stack, sp);
+			cur = bvh_pop(bv, stack, sp);
 		} else if (kBvhQuorum == 0) break;
 	}
 	PT_TIME_END(4);
@@ -648,7 +707,7 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 		PT_TIME_BEGIN();
 		if (pend != kNone) bvh_leaf(bv.leaves, (uint32_t)~pend, bv.det_bounded, o, d, best_t, hit_tri);
 		if (cur < 0) {
-			PT_CHECK(((uint32_t)~cur >> 3) + ((uint32_t)~cur & 7u) < bv.n_tris && sp >= 0 && sp <= bv.stack_depth, { cur = kBvhDone; sp = 0; return; });
+			PT_CHECK(((uint32_t)~cur >> 3) + ((uint32_t)~cur & 7u) < bv.n_tris && sp >= 0 && sp <= bv.stack_total, { cur = kBvhDone; sp = 0; return; });
 			if (COLLECT) {
 				// triangle by triangle (a list entry is a leaf code of ONE triangle), and only those the pixel's camera rays can hit at
 				// all: corners_can_hit, the rejection tests of Functions.cuh:72-86 at the patch's four corners (what primary_need_mask
@@ -665,7 +724,7 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 					col->n++;
 				}
 			} else bvh_leaf(bv.leaves, (uint32_t)~cur, bv.det_bounded, o, d, best_t, hit_tri);
-			cur = bvh_pop(stack, sp);
+			cur = bvh_pop(bv, stack, sp);
 		}
 		PT_TIME_END(5);
 	}
@@ -679,7 +738,8 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 }
 
 __device__ __forceinline__ void bvh_intersect(const BvhView& bv, Vec3 o, Vec3 d, float& best_t, uint32_t& hit_tri,
-                                              uint32_t* stack) {
+                                              uint32_t* s_stack) {
+	BvhStack stack = bvh_stack_at(s_stack);
 	BvhRay r = bvh_ray_setup(bv, o, d, best_t, bv.first_free);
 	int32_t cur;
 	int sp;
@@ -705,7 +765,7 @@ __device__ __forceinline__ void extend_bvh_block(const BvhView& bv, float4 origi
                                                  uint32_t count, uint32_t capacity, uint2* __restrict__ hit, uint32_t* s_stack, uint32_t* s_next) {
 	const uint32_t G = gridDim.x;
 	const uint32_t lane = threadIdx.x & 63u;
-	uint32_t* stack = s_stack + threadIdx.x;
+	BvhStack stack = bvh_stack_at(s_stack);
 	uint32_t q = 0, tri = kNoHit;
 	float best = 0.0f;
 	Vec3 o{ 0, 0, 0 }, d{ 0, 0, 0 };
@@ -1013,7 +1073,7 @@ __device__ __forceinline__ PixelCone pixel_cone(const FrameDev& f, uint32_t px, 
 // One pixel per lane; every lane of the wave calls it (bvh_round's ballots), `active` false: takes part idly.  lists: pixel_count
 // counts, then PT_PRIMARY_LIST_LEAVES rows of pixel_count leaf codes.  `stack`: the lane's column of the traversal stack.
 __device__ __forceinline__ void bvh_collect_pixel(const BvhView& bv, const FrameDev& f, bool active, uint32_t px, uint32_t py, uint32_t li,
-                                                  uint32_t* __restrict__ lists, uint32_t pixel_count, uint32_t* stack) {
+                                                  uint32_t* __restrict__ lists, uint32_t pixel_count, BvhStack& stack) {
 	const PixelCone pc = pixel_cone(f, px, py);
 	// a cone too wide for the bound to mean anything (a camera inside out, a 2 x 2 image): the pixel walks per ray
 	const bool ok = active && pc.dmin > 0.05f && pc.chord < 0.05f;

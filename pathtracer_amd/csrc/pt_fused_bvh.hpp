@@ -69,7 +69,7 @@ __device__ __forceinline__ void fused_bvh_block(const FusedBvhCtx& c, uint32_t r
                                                 uint32_t* s_stack, uint32_t* s_next, uint32_t& n_rays, uint32_t& n_diffuse) {
 	const FrameDev& f = c.f;
 	const uint32_t lane = threadIdx.x & 63u;
-	uint32_t* stack = s_stack + threadIdx.x;
+	BvhStack stack = bvh_stack_at(s_stack);
 	const bool extended = f.shading == PT_SHADING_EXTENDED;
 	// the lane's pixel ...
 	bool have_pixel = false;

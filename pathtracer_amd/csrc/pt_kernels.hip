@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 came
 	if (BVH && FIRST && lists != nullptr) {
 		// camera rays with their pixels' leaf lists (pt_device.hpp, bvh_collect_pixel): no node steps; the few pixels whose lists
 		// overflowed walk, the wave's lanes together (path id == slot at bounce 0, local pixel = path id % pixel_count)
-		uint32_t* stack = s_stack + threadIdx.x;
+		BvhStack stack = bvh_stack_at(s_stack);
 		const Vec3 o{ origin.x, origin.y, origin.z };
 		for (uint32_t j0 = 0; j0 < count; j0 += kBlock) {
 			const uint32_t q = queue_slot(j0, G) + threadIdx.x;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_primary_lists(FrameDev f, const u
                                                              uint32_t* __restrict__ lists) {
 	extern __shared__ float4 s_dyn[];
 	if (!scene_guard(scene, n_tris, true)) return;
-	uint32_t* stack = reinterpret_cast<uint32_t*>(s_dyn) + threadIdx.x;
+	BvhStack stack = bvh_stack_at(reinterpret_cast<uint32_t*>(s_dyn));
 	const BvhView bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
 	for (uint32_t li0 = blockIdx.x * kBlock; li0 < f.pixel_count; li0 += gridDim.x * kBlock) {
 		const uint32_t li = li0 + threadIdx.x;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 			if (alive) {
 				n_rays++;
 				uint32_t tri = kNoHit;
-				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack);
 				else if (use_prim) intersect_range_primary(tris, s_prim, n_tris, det_bounded, d, best, tri, need);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				alive = shade_hit(tri);
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 				n_rays++;
 				uint32_t tri = kNoHit;
 				if (extended) best = FLT_MAX;            // EXTENDED: every bounce finds its own closest hit
-				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack + threadIdx.x);
+				if (BVH) bvh_intersect(bv, o, d, best, tri, s_stack);
 				else intersect_range(tris, 0, n_tris, det_bounded, o, d, best, tri);
 				alive = shade_hit(tri);
 			}
@@ -1134,17 +1134,27 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 	{
 		// bounding sphere + (large scenes) the BVH: see pt_bvh.hpp for why the result stays the brute-force one
 		if (n_triangles > g_bvh_min_tris) {
-			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles, bvh_stack_depth(n_triangles));
-			if (bvh.nodes.size() > n_triangles) return fail(PT_ERR_LIMIT, "scene_pack: BVH larger than its reservation");
+			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles, bvh_depth_budget(n_triangles));
+			if (bvh.nodes.size() > n_triangles || bvh.nodes4.size() > n_triangles) return fail(PT_ERR_LIMIT, "scene_pack: BVH larger than its reservation");
 			// (two trees: the marker that leads from the first to the second takes one level of the stack under the first one's walk)
-			const uint32_t levels = bvh_stack_depth(n_triangles), marker = bvh.classes.second_root != 0u ? 1u : 0u;
+			const uint32_t levels = bvh_stack_total(n_triangles), marker = bvh.classes.second_root != 0u ? 1u : 0u;
+			float glo[3], cell;
+			bvh_grid(bvh.center, bvh.radius, glo, cell);
+#if PT_BVH_WIDE
+			static_assert(ptbvh::kEmptyChild == kBvhEmpty && sizeof(ptbvh::QNode4) == kBvhNodeBytes, "pt_bvh.hpp and pt_device.hpp disagree on the wide node");
+			if (bvh_stack_total(n_triangles) > bvh_stack_depth(n_triangles) + kBvhSpill) return fail(PT_ERR_LIMIT, "scene_pack: BVH deeper than the traversal stack and its overflow");
+			if (ptbvh::stack_need4(bvh.nodes4, 0) + marker > levels || (marker && ptbvh::stack_need4(bvh.nodes4, bvh.classes.second_root) > levels))
+				return fail(PT_ERR_LIMIT, "scene_pack: BVH deeper than the traversal stack");
+			hdr.n_nodes = (uint32_t)bvh.nodes4.size();
+			std::vector<ptbvh::QNode4> qnodes = ptbvh::quantize4(bvh.nodes4, glo, cell);
+			std::memcpy(base + hdr.bvh_offset, qnodes.data(), qnodes.size() * sizeof(ptbvh::QNode4));
+#else
 			if (ptbvh::inner_depth(bvh.nodes, 0) + marker > levels || (marker && ptbvh::inner_depth(bvh.nodes, bvh.classes.second_root) > levels))
 				return fail(PT_ERR_LIMIT, "scene_pack: BVH deeper than the traversal stack");
 			hdr.n_nodes = (uint32_t)bvh.nodes.size();
-			float glo[3], cell;
-			bvh_grid(bvh.center, bvh.radius, glo, cell);
 			std::vector<ptbvh::QNode> qnodes = ptbvh::quantize(bvh.nodes, glo, cell);
 			std::memcpy(base + hdr.bvh_offset, qnodes.data(), qnodes.size() * sizeof(ptbvh::QNode));
+#endif
 			std::memcpy(base + hdr.leaf_offset, bvh.tris.data(), bvh.tris.size() * sizeof(ptbvh::LeafTri));
 			static_assert(sizeof(ptbvh::ClassBlock) == kBvhClassBytes && ptbvh::kMaxClasses == kBvhMaxClasses && ptbvh::kKappaRho == kBvhKappaRho && ptbvh::kRhoMin == kBvhRhoMin,
 			              "pt_bvh.hpp and pt_device.hpp disagree on the normal classes");

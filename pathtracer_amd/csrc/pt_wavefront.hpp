@@ -424,7 +424,7 @@ __device__ __forceinline__ void bounce_tail_block(const ShadeCtx& c, const BvhVi
 	const FrameDev& f = c.f;
 	const uint32_t G = gridDim.x;
 	const uint32_t lane = threadIdx.x & 63u;
-	uint32_t* stack = s_stack + threadIdx.x;
+	BvhStack stack = bvh_stack_at(s_stack);
 	const bool extended = f.shading == PT_SHADING_EXTENDED;
 	bool has_path = false, exhausted = false;
 	uint32_t bounce = 0;                 // of the ray the lane is walking

@@ -135,14 +135,15 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     hdr_u = raw[:64].view(np.uint32)
     hdr_f = raw[:64].view(np.float32)
     n_tris, n_nodes, bvh_off, leaf_off = int(hdr_u[0]), int(hdr_u[6]), int(hdr_u[7]), int(hdr_u[8])
-    assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 32 * n_tris
+    assert n_tris == len(T) and 0 < n_nodes <= n_tris and bvh_off % 64 == 0 and leaf_off == bvh_off + 64 * n_tris
     assert hdr_f[12] > 0 and hdr_f[13] > 0                       # radius, kappa_root
-    # QNode, 32 bytes = two half nodes of {3 words {lo, hi} uint16 grid coordinates, child word}; the grid is bvh_grid(center, radius)
+    # QNode4, 64 bytes = four half nodes of {3 words {lo, hi} uint16 grid coordinates, child word}, unused slots hold 0x7FFFFFFD behind an
+    # inside-out box; the grid is bvh_grid(center, radius)
     balanced, k = 0, n_tris
     while k > 2:
         k, balanced = (k + 1) // 2, balanced + 1
     # the blob: header, triangles, materials | nodes | leaf records | normal classes
-    assert n == bvh_off + (32 + 64) * n_tris + 320
+    assert n == bvh_off + (64 + 64) * n_tris + 320
     # ClassBlock: {n_classes, all_classified, pad, pad} + 8 x {axis * cos(h), sin(h)}: every triangle's plane lies in one of the
     # cones (half-angle h around the axis), so |dhat . axis| cos(h) - sin(h) bounds |cos(ray, normal)| from below
     cb = raw[leaf_off + 64 * n_tris:leaf_off + 64 * n_tris + 320]
@@ -169,8 +170,8 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
         members = nrm[np.abs(nrm @ (cls[k, :3] / np.linalg.norm(cls[k, :3]))) > np.cos(0.15)]
         rho_k = np.abs(dirs @ cls[k, :3]) - cls[k, 3]
         assert (rho_k[:, None] <= np.abs(dirs @ members.T) + 1e-12).all()
-    nodes_q = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.uint16).reshape(n_nodes, 16)
-    nodes_i = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.int32).reshape(n_nodes, 8)
+    nodes_q = raw[bvh_off:bvh_off + 64 * n_nodes].view(np.uint16).reshape(n_nodes, 4, 8)
+    nodes_i = raw[bvh_off:bvh_off + 64 * n_nodes].view(np.int32).reshape(n_nodes, 4, 4)
     half = np.float32(1.0001) * hdr_f[12] + np.float32(1e-6)
     glo = (hdr_f[9:12] - half).astype(np.float64)
     cell = float(np.float32(np.float32(2.0) * half) / np.float32(65534.0))
@@ -183,8 +184,10 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
     kappa_root = float(hdr_f[13])
 
     deepest = [0]
+    need = [0]
+    EMPTY = 0x7FFFFFFD
 
-    def visit(child, lo, hi, depth=1):
+    def visit(child, lo, hi, depth=1, held=0):
         """checks containment: a quantised box holds its subtree's vertices EXACTLY (corners rounded outward, no tolerance)
         and lies inside its parent's"""
         if child < 0:
@@ -200,21 +203,32 @@ def test_bvh_blob_is_a_valid_hierarchy(pt):
                 assert np.array_equal(leaves[k, 0:3], pts[0]) and np.array_equal(leaves[k, 3:6], e0) and np.array_equal(leaves[k, 6:9], e1)
                 assert kappa_root >= 16 * 2.0**-24 / 1e-6 * np.linalg.norm(e0) * np.linalg.norm(e1) * (1 - 1e-5)
             return
-        q, ni = nodes_q[child].astype(np.float64), nodes_i[child]
-        lo0, hi0, lo1, hi1 = glo + q[0:6:2] * cell, glo + q[1:6:2] * cell, glo + q[8:14:2] * cell, glo + q[9:14:2] * cell
-        assert (lo0 >= lo).all() and (hi0 <= hi).all() and (lo1 >= lo).all() and (hi1 <= hi).all()
-        # outward rounding costs at most one cell per face
         deepest[0] = max(deepest[0], depth)
-        visit(int(ni[3]), lo0, hi0, depth + 1)
-        visit(int(ni[7]), lo1, hi1, depth + 1)
+        slots = [c for c in range(4) if int(nodes_i[child, c, 3]) != EMPTY]
+        assert slots == list(range(len(slots))) and len(slots) >= 2          # children first, empty slots last
+        for c in range(len(slots), 4):
+            q = nodes_q[child, c]
+            assert (q[0:6:2] == 65535).all() and (q[1:6:2] == 0).all()      # inside out
+        # a walk defers up to (children - 1) of a node's children while it descends into one of them
+        held += len(slots) - 1
+        need[0] = max(need[0], held)
+        for c in slots:
+            q = nodes_q[child, c].astype(np.float64)
+            clo, chi = glo + q[0:6:2] * cell, glo + q[1:6:2] * cell
+            # outward rounding costs at most one cell per face
+            assert (clo >= lo).all() and (chi <= hi).all()
+            visit(int(nodes_i[child, c, 3]), clo, chi, depth + 1, held)
 
     import sys
     sys.setrecursionlimit(10000)
     visit(0, np.full(3, -np.inf), np.full(3, np.inf))
     assert (seen == 1).all()
-    # the traversal's stack is sized from the triangle count alone (bvh_stack_depth: balanced depth of 2-triangle leaves + 3
-    # levels of slack for surface-area splits); the builder must stay inside it
-    assert 0 < deepest[0] <= balanced + 3
+    # the traversal's stack is sized from the triangle count alone (bvh_depth_budget: balanced depth of 2-triangle leaves + 3
+    # levels of slack for surface-area splits; a wide node stands for two binary levels and defers up to three children:
+    # bvh_stack_total, of which bvh_stack_depth = the budget live in LDS and at most 16 in private memory); the builder must stay inside it
+    budget = balanced + 3
+    assert 0 < deepest[0] <= (budget + 1) // 2
+    assert need[0] <= 3 * ((budget + 1) // 2) and 3 * ((budget + 1) // 2) + 1 - budget <= 16
     # the knob: brute force only
     assert lib.pt_hip_set_bvh_threshold(0xFFFFFFFF) == 0
     try:

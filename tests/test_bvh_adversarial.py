@@ -293,7 +293,7 @@ def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
     second_root, first_is_free, n_first = int(cb[3]), int(cb[68]), int(cb[69])
     free_max_edge = float(cb[70:71].view(np.float32)[0])
     assert 0 < second_root < n_nodes and first_is_free == 0 and n_first == 300
-    nodes_i = raw[bvh_off:bvh_off + 32 * n_nodes].view(np.int32).reshape(n_nodes, 8)
+    nodes_i = raw[bvh_off:bvh_off + 64 * n_nodes].view(np.int32).reshape(n_nodes, 4, 4)      # QNode4: four {box words x, y, z; child}
     leaves = raw[leaf_off:leaf_off + 64 * n_tris].view(np.float32).reshape(n_tris, 16)
     orig = leaves[:, 9].view(np.uint32)
     assert sorted(orig[:300].tolist()) == list(range(300)) and sorted(orig[300:].tolist()) == list(range(300, n_tris))
@@ -309,7 +309,7 @@ def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
             assert c not in inner
             inner.add(c)
             deepest = max(deepest, depth)
-            todo += [(int(nodes_i[c, 3]), depth + 1), (int(nodes_i[c, 7]), depth + 1)]
+            todo += [(int(nodes_i[c, k, 3]), depth + 1) for k in range(4) if int(nodes_i[c, k, 3]) != 0x7FFFFFFD]
         return seen, deepest, inner
     a, depth_a, inner_a = leaves_of(0)
     b, depth_b, inner_b = leaves_of(second_root)
@@ -318,7 +318,8 @@ def test_classified_and_free_triangles_live_in_trees_of_their_own(pt):
     balanced, k = 0, n_tris
     while k > 2:
         k, balanced = (k + 1) // 2, balanced + 1
-    assert depth_a + 1 <= balanced + 3 and depth_b + 1 <= balanced + 3
+    # (a wide node stands for two binary levels; two trees: each built one binary level inside the budget)
+    assert depth_a <= (balanced + 3) // 2 and depth_b <= (balanced + 3) // 2
     P = np.array([v[:3] for v in V], dtype=np.float64)
     tri = np.array([t[:3] for t in T])[300:]
     edges = np.concatenate([np.linalg.norm(P[tri[:, i]] - P[tri[:, j]], axis=1) for i, j in ((0, 1), (0, 2), (1, 2))])

@@ -19,6 +19,7 @@ import scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHECK = os.path.join(ROOT, "tests", "host", "bvh_host_check")
+CHECK_SPILL = os.path.join(ROOT, "tests", "host", "bvh_host_check_spill")     # three stack levels in "LDS", the rest in BvhStack::spill
 WAVE_CHECK = os.path.join(ROOT, "tests", "host", "extend_wave_check")
 FLT_MAX = np.finfo(np.float32).max
 
@@ -83,8 +84,9 @@ def scene_by_name(name):
 
 @pytest.mark.parametrize("name,n_rays,camera", [("synthetic-700", 6000, (0.0, 0.0, 0.0)), ("synthetic-1500", 6000, (0.0, 0.0, 0.0)), ("soup-900", 5000, (0.0, 0.0, 0.0)),
                                                 ("synthetic-10000", 1500, (0.2, -0.1, 0.05)), ("mixed", 4000, (0.2, -0.1, 0.05))])
-def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, camera):
-    if not os.path.exists(CHECK):
+@pytest.mark.parametrize("check", [CHECK, CHECK_SPILL], ids=["lds", "spill"])
+def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, camera, check):
+    if not os.path.exists(check):
         pytest.skip("tests/host/bvh_host_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
     V, T, M = scene_by_name(name)
     blob, rays = tmp_path / "scene.blob", tmp_path / "rays.f32"
@@ -92,7 +94,7 @@ def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, cam
     make_rays(n_rays, 7, camera).tofile(rays)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     env.pop("LD_PRELOAD", None)          # ASan must come first in the library list of its own process
-    r = subprocess.run([CHECK, str(blob), str(rays)] + [str(c) for c in camera], capture_output=True, text=True, env=env, timeout=300)
+    r = subprocess.run([check, str(blob), str(rays)] + [str(c) for c in camera], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     fields = r.stdout.split()
     assert int(fields[1]) == n_rays and int(fields[3]) > n_rays // 3 and int(fields[5]) == 0, r.stdout
