@@ -236,22 +236,36 @@ __host__ __device__ inline void bvh_grid(const float center[3], float radius, fl
 	cell = (2.0f * half) / 65534.0f;
 }
 
+#ifdef PT_TRI_COUNT
+// debug build only (tools/tri_stage_counts.py): how many lanes of a wave are still in a triangle test at each of its stages --
+// slots 0..3: lanes entering the determinant, the u, the v and the t part; 4..7: wave-level trips through each part
+__device__ unsigned long long g_tri_count[8];
+#define PT_TRI_STAGE(k, pred) do { unsigned long long w_ = __ballot(pred); if (w_ && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(w_)) { \
+	atomicAdd(&g_tri_count[k], (unsigned long long)__popcll(w_)); atomicAdd(&g_tri_count[4 + (k)], 1ull); } } while (0)
+#else
+#define PT_TRI_STAGE(k, pred) ((void)0)
+#endif
+
 // Moeller-Trumbore with culling, Functions.cuh:56-89.  Returns true and t unless the reference
 // returns NO_INTERSECTION.  e0/e1 are the precomputed v1-v0 / v2-v0 (same fp32 subtraction).
 // det_bounded (wave-uniform, SceneHeader::flags): every |e0|*|e1| of the scene is below 2^100, so for |d| < 2^20
 // (the path's own directions have |d| <= 1) EPS <= det < 2^121 here and rcp_newton IS the division.
 __device__ __forceinline__ bool ray_triangle(Vec3 o, Vec3 d, Vec3 v0, Vec3 e0, Vec3 e1, bool det_bounded, float& t) {
+	PT_TRI_STAGE(0, true);
 	Vec3 h = cross3(d, e1);
 	float det = dot3(e0, h);
 	if (det < kEpsilon) return false;            // :72
+	PT_TRI_STAGE(1, true);
 	float f;                                     // :77  1.0f / det
 	if (det_bounded) f = rcp_newton(det); else f = 1.0f / det;
 	Vec3 s = Vec3{ o.x - v0.x, o.y - v0.y, o.z - v0.z };
 	float u = f * dot3(s, h);                    // :80
 	if (u < 0.0f || u > 1.0f) return false;
+	PT_TRI_STAGE(2, true);
 	Vec3 q = cross3(s, e0);
 	float v = f * dot3(d, q);                    // :84
 	if (v < 0.0f || u + v > 1.0f) return false;
+	PT_TRI_STAGE(3, true);
 	t = f * dot3(e1, q);                         // :87
 	return true;
 }

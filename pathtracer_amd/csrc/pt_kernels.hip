@@ -1520,6 +1520,13 @@ int pt_hip_render_wavefront_noalloc(const pt_frame* frame, const void* scene_blo
 	                             rng, mean, ws, (size_t)PT_NOALLOC_SCRATCH_BYTES, stats, stream);
 }
 
+#ifdef PT_TRI_COUNT
+int pt_hip_debug_tri_counts(unsigned long long* out, int reset) {
+	if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_tri_count), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_tri_count), z, sizeof(z)) != hipSuccess) return -1; }
+	return 0;
+}
+#endif
 #if defined(PT_BVH_COUNT) || defined(PT_BVH_TIME) || defined(PT_BVH_CHECK)
 int pt_hip_debug_bvh_counts(unsigned long long* out, int reset) {
 	if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_bvh_count), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
