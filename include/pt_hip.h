@@ -140,12 +140,12 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* waits for 
 /* ---- scene: Vertex/Triangle/Material arrays (Structures.cuh:43-69, upload PathTracer.cu:48-77)
  * packed once on the host into the device blob the kernels stage in LDS: per triangle
  * {v0, e0=v1-v0, e1=v2-v0, n=cross(e0,e1), materialIdx}, per material {type, color}; above PT_BVH_DEFAULT_MIN_TRIANGLES
- * triangles also a BVH (32-byte nodes + 64-byte leaf records).
+ * triangles also a BVH (64-byte nodes of four children + 64-byte leaf records).
  * Validates vertex and material indices.  The blob is position independent: copy it to the
  * device with pt_hip_memcpy_h2d.  Entry points that take `scene_blob` also take the triangle and
  * material counts it was packed with. */
 /* Process-wide tuning knob for scenes packed FROM NOW ON: those with more than `min_triangles` triangles get a BVH
- * (default 512, the measured crossover; 0xFFFFFFFF = always brute force like the reference).  Whether a packed blob
+ * (default PT_BVH_DEFAULT_MIN_TRIANGLES, the measured crossover; 0xFFFFFFFF = always brute force like the reference).  Whether a packed blob
  * carries one is recorded in the blob (pt_hip_scene_has_bvh) and handed to the kernels' launchers as
  * PT_FRAME_SCENE_BVH in pt_frame.flags; blobs packed earlier stay valid.  Results do not depend on it. */
 int pt_hip_set_bvh_threshold(uint32_t min_triangles);
@@ -302,6 +302,12 @@ int pt_hip_comm_ranks(void* comm, int* ranks);
  * float4, shard-major in virtual-shard order) receives this rank's slice of every shard: grouped ncclSend/ncclRecv, every
  * xGMI link busy at once; (2) the fixed-order tree of pt_hip_combine_shards over the local*ranks shards into
  * image[rank*slice_pixels ..]; (3) ncclAllGather in place: every rank ends with the whole image (pitch_pixels float4). */
+/* The send / receive layout of step (1) below, as data: local*ranks entries, entry j*ranks + r = what this rank exchanges with rank
+ * r for its local shard j -- `count` floats from local_shards + send_offset to rank `peer`, `count` floats from rank `peer` to
+ * stacked + recv_offset (offsets in floats).  pt_hip_comm_exchange_combine executes exactly this plan over RCCL; a host with a
+ * transport of its own, and the gloo test of the layout (tests/test_sample_split_gloo.py), execute it over theirs.  Host code only. */
+typedef struct { uint32_t peer, reserved; uint64_t send_offset, recv_offset, count; } pt_exchange_step;
+int pt_hip_comm_exchange_plan(int rank, int ranks, uint32_t local, size_t slice_pixels, pt_exchange_step* steps);
 int pt_hip_comm_exchange_combine(void* comm, int rank, int ranks, const void* local_shards, uint32_t local,
                                  size_t slice_pixels, void* stacked, void* image, void* stream);
 

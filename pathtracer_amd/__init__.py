@@ -183,6 +183,7 @@ SYMBOLS = {
     "pt_hip_comm_create": (C.c_int, [C.POINTER(_VP), _VP, C.c_int, C.c_int]),
     "pt_hip_comm_destroy": (C.c_int, [_VP]),
     "pt_hip_comm_ranks": (C.c_int, [_VP, C.POINTER(C.c_int)]),
+    "pt_hip_comm_exchange_plan": (C.c_int, [C.c_int, C.c_int, _U32, _SZ, _VP]),
     "pt_hip_comm_exchange_combine": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _U32, _SZ, _VP, _VP, _VP]),
 }
 

@@ -1746,13 +1746,31 @@ int pt_hip_comm_ranks(void* comm, int* ranks) {
 	RCCL_TRY(rccl().CommCount((RcclComm)comm, ranks));
 	return PT_OK;
 }
+int pt_hip_comm_exchange_plan(int rank, int ranks, uint32_t local, size_t slice_pixels, pt_exchange_step* steps) {
+	if (!steps) return fail(PT_ERR_INVALID, "comm_exchange_plan: null pointer");
+	if (ranks < 1 || rank < 0 || rank >= ranks || local == 0) return fail(PT_ERR_INVALID, "comm_exchange_plan: bad rank / ranks / local");
+	const uint64_t slice_floats = (uint64_t)slice_pixels * 4u, pitch_floats = slice_floats * (uint64_t)ranks;
+	for (uint32_t j = 0; j < local; j++)
+		for (int r = 0; r < ranks; r++) {
+			// slice r of local shard j (= virtual shard rank + j*ranks) -> rank r; from rank r: my slice of ITS shard r + j*ranks,
+			// which is position j*ranks + r of `stacked`: shard-major in virtual-shard order
+			pt_exchange_step& st = steps[(size_t)j * ranks + r];
+			st.peer = (uint32_t)r;
+			st.reserved = 0;
+			st.send_offset = (uint64_t)j * pitch_floats + (uint64_t)r * slice_floats;
+			st.recv_offset = ((uint64_t)j * ranks + r) * slice_floats;
+			st.count = slice_floats;
+		}
+	return PT_OK;
+}
+
 int pt_hip_comm_exchange_combine(void* comm, int rank, int ranks, const void* local_shards, uint32_t local,
                                  size_t slice_pixels, void* stacked, void* image, void* stream) {
 	if (!local_shards || !stacked || !image) return fail(PT_ERR_INVALID, "comm_exchange_combine: null pointer");
 	if (ranks < 1 || rank < 0 || rank >= ranks || local == 0) return fail(PT_ERR_INVALID, "comm_exchange_combine: bad rank / ranks / local");
 	if (!comm && ranks > 1) return fail(PT_ERR_STATE, "comm_exchange_combine: more than one rank needs a communicator");
 	hipStream_t s = (hipStream_t)stream;
-	const size_t slice_floats = slice_pixels * 4, pitch_floats = slice_floats * (size_t)ranks;
+	const size_t slice_floats = slice_pixels * 4;
 	const float* src = (const float*)local_shards;
 	float* st = (float*)stacked;
 	if (!comm) {
@@ -1763,14 +1781,15 @@ int pt_hip_comm_exchange_combine(void* comm, int rank, int ranks, const void* lo
 		int count = 0;
 		RCCL_TRY(rccl().CommCount((RcclComm)comm, &count));
 		if (count != ranks) return fail(PT_ERR_INVALID, "comm_exchange_combine: the communicator has " + std::to_string(count) + " ranks, not " + std::to_string(ranks));
+		// (the layout is pt_hip_comm_exchange_plan's: tests/test_sample_split_gloo.py runs the same plan over gloo)
+		std::vector<pt_exchange_step> plan((size_t)local * ranks);
+		if (int rc = pt_hip_comm_exchange_plan(rank, ranks, local, slice_pixels, plan.data())) return rc;
 		RCCL_TRY(rccl().GroupStart());
-		for (uint32_t j = 0; j < local; j++)
-			for (int r = 0; r < ranks; r++) {
-				// slice r of local shard j (= virtual shard rank + j*ranks) -> rank r; from rank r: my slice of ITS shard r + j*ranks
-				int e1 = rccl().Send(src + (size_t)j * pitch_floats + (size_t)r * slice_floats, slice_floats, kNcclFloat, r, (RcclComm)comm, s);
-				int e2 = rccl().Recv(st + ((size_t)j * ranks + r) * slice_floats, slice_floats, kNcclFloat, r, (RcclComm)comm, s);
-				if (e1 || e2) { rccl().GroupEnd(); return rccl_fail(e1 ? e1 : e2, "ncclSend/ncclRecv"); }
-			}
+		for (const pt_exchange_step& step : plan) {
+			int e1 = rccl().Send(src + step.send_offset, step.count, kNcclFloat, (int)step.peer, (RcclComm)comm, s);
+			int e2 = rccl().Recv(st + step.recv_offset, step.count, kNcclFloat, (int)step.peer, (RcclComm)comm, s);
+			if (e1 || e2) { rccl().GroupEnd(); return rccl_fail(e1 ? e1 : e2, "ncclSend/ncclRecv"); }
+		}
 		RCCL_TRY(rccl().GroupEnd());
 	}
 	float* mine = (float*)image + (size_t)rank * slice_floats;
