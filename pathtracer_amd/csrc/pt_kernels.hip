@@ -506,8 +506,11 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(FrameDev f, const unsigned 
 
 // BVH scenes: the rays of bounce `entry_bounce` and every bounce after them in one persistent launch (pt_wavefront.hpp,
 // bounce_tail_block).  counts: row entry_bounce = the block's queue entries (read), rows above it = the rays of the later bounces (written).
+// (round 3, wide nodes, 10 092 / 99 372 triangles, Mrays/s: 4 waves per SIMD 16 364 / 13 799, 5: 16 352 / 13 824, 6: 16 236 / 13 620, 8 (64
+// registers, spills): 15 522 / 13 138; entry bounce off / 1 / 2 / 3 / 4: 15 769 / 15 680 / 16 236 / 16 118 / 15 971 and 12 696 / 13 369 /
+// 13 620 / 13 114 / 12 966; service at 16 / 24 / 32 / 48 waiting lanes: 15 939 / 16 231 / 16 474 / 16 620 and 13 756 / 13 825 / 13 905 / 13 865)
 #ifndef PT_TAIL_WAVES
-#define PT_TAIL_WAVES 6
+#define PT_TAIL_WAVES 5
 #endif
 #ifndef PT_TAIL_ENTRY
 #define PT_TAIL_ENTRY 2
