@@ -618,8 +618,14 @@ struct BvhStack {
 	uint32_t spill[kBvhSpill];
 };
 __device__ __forceinline__ BvhStack bvh_stack_at(uint32_t* s_stack) { BvhStack st; st.lds = s_stack + threadIdx.x; return st; }
+#ifdef PT_BVH_TRACK_DEPTH          // tests/host only: the deepest any walk's stack got, to show that a test reaches the private part
+static int g_bvh_deepest = 0;
+#endif
 __device__ __forceinline__ void bvh_push(const BvhView& bv, BvhStack& st, int& sp, uint32_t v) {
 	PT_CHECK(sp < bv.stack_total, {});
+#ifdef PT_BVH_TRACK_DEPTH
+	if (sp + 1 > g_bvh_deepest) g_bvh_deepest = sp + 1;
+#endif
 	if (!PT_BVH_WIDE || sp < bv.stack_depth) { if (sp < bv.stack_depth) { st.lds[sp * 256] = v; sp++; } }     // (never full: scene_pack checks the tree against it)
 	else if (sp < bv.stack_total && (uint32_t)(sp - bv.stack_depth) < kBvhSpill) { st.spill[sp - bv.stack_depth] = v; sp++; }
 }

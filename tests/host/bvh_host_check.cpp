@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
+#define PT_BVH_TRACK_DEPTH
 #include "pt_device.hpp"
 
 using namespace ptd;
@@ -54,7 +55,7 @@ int main(int argc, char** argv) {
 			bad++;
 		}
 	}
-	std::printf("rays %zu hits %zu mismatches %zu\n", n_rays, hits, bad);
+	std::printf("rays %zu hits %zu mismatches %zu deepest %d lds_levels %zu\n", n_rays, hits, bad, g_bvh_deepest, depth);
 	std::free(stack);
 	std::free(blob);
 	return bad ? 1 : 0;

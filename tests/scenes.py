@@ -151,3 +151,20 @@ def triangle_soup(n_triangles, seed):
         r = rng.uniform()
         T.append((base, base + 1, base + 2, 3 if r < 0.15 else (2 if r < 0.25 else int(rng.uniform() * 2) % 2)))
     return V, T, M
+
+
+def heap_of_large_triangles(n_triangles, seed):
+    """Triangles that each span most of the scene, in every orientation: every bounding box overlaps every other and a ray enters
+    nearly all of them, so a walk of the BVH defers a sibling (three, with four children per node) at every level -- the scene that
+    fills the traversal stack to its bound (pt_device.hpp, BvhStack: the levels beyond the LDS part live in private memory)."""
+    rng = SplitMix64(seed)
+    V, T = [], []
+    M = [(DIFFUSE, (0.8, 0.7, 0.6, 1.0)), (DIFFUSE, (0.3, 0.5, 0.9, 1.0)), (EMISSIVE, (6.0, 5.0, 4.0, 1.0))]
+    for _ in range(n_triangles):
+        centre = np.array([(rng.uniform() - 0.5) * 0.2, (rng.uniform() - 0.5) * 0.2, 1.0 + (rng.uniform() - 0.5) * 0.2])
+        base = len(V)
+        for _k in range(3):
+            p = centre + (np.array([rng.uniform(), rng.uniform(), rng.uniform()]) - 0.5) * 1.6
+            V.append((float(np.float32(p[0])), float(np.float32(p[1])), float(np.float32(p[2])), 1.0))
+        T.append((base, base + 1, base + 2, 2 if rng.uniform() < 0.1 else int(rng.uniform() * 2) % 2))
+    return V, T, M

@@ -40,3 +40,27 @@ def test_room_with_a_tessellated_ball(pt, oracle, name, engine):
     diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
     assert not diff.any(), f"{name}: {int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
     assert np.array_equal(rng, ref_rng) and got.rays == st.rays
+
+
+@pytest.mark.parametrize("name,engine,strided", [("fused", 1, False), ("wavefront", 0, False), ("wavefront strided", 0, True)])
+def test_heap_of_large_triangles_fills_the_traversal_stack(pt, oracle, name, engine, strided):
+    """1500 triangles that each span the scene: every box overlaps every other, a walk defers three children at every level of the
+    four-wide tree and its stack grows past the levels kept in LDS into the private part (BvhStack::spill) -- the host harness shows
+    that it does (tests/test_bvh_host.py, heap-1500: deepest > lds_levels), this is the same scene on the GPU: every pixel against the
+    oracle's loop over all triangles."""
+    import scenes
+    V, T, M = scenes.heap_of_large_triangles(1500, 9)
+    w, h, spp, depth = 64, 36, 2, 4
+    mode = dict(rng_mode=oracle.RNG_STRIDED, stride=2 + 33 * depth) if strided else {}
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, **mode), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        if strided:
+            tr.set_options(engine=engine, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=2 + 33 * depth, samples_per_pass=2)
+        else:
+            tr.set_options(engine=engine, depth=depth)
+        tr.render(spp)
+        img, got = tr.readback(), tr.stats()
+    diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+    assert not diff.any(), f"{name}: {int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+    assert got.rays == st.rays and st.rays > w * h * spp
