@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))      # tests/scenes.py: the deterministic scenes of BASELINE.json's configs
 
 WIDTH, HEIGHT, SPP_PER_STEP, DEPTH = 1920, 1080, 64, 10
+SETTLE_SECONDS = 0.3          # untimed renders before the timed steps, see measure()
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles per SIMD at 2.4 GHz (same guide: v_fma_f32
 # 2 cycles on the SIMD-32; tools/valu_microbench.hip measures 2.4-2.6 at the clock the chip holds under load)
@@ -181,7 +182,7 @@ def valu_roofline(counters, key, kernel_ms, sha):
             "stale": counters.get("sha") != sha}
 
 
-def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples_per_pass=16, sequential=False, min_seconds=0.0, device=0):
+def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples_per_pass=16, sequential=False, min_seconds=0.0, device=0, settle_seconds=SETTLE_SECONDS):
     """steps x (one pt_render of `spp` samples); returns wall ms per step, device ms per step, rays per step, the tracer's image"""
     scene_name, depth, stride, _ = WORKLOADS[workload]
     tracer = pt.PathTracer(w, h, device=device)
@@ -194,9 +195,16 @@ def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples
         tracer.set_options(engine=eng, depth=depth, rng_mode=pt.PT_RNG_STRIDED, stride=stride, samples_per_pass=samples_per_pass)
     # the plugin measures its candidates (fused in step / out of step, wavefront under AUTO) on the first renders after a
     # restart: those come first, untimed and on top of the W warm-up steps, so that the timed steps run the decided kernels
+    # ... and the device gets SETTLE_SECONDS of the same renders to reach the clock it holds under this load: the 20 steps the
+    # driver times are 20 ms of work, and measured from a cold start they run 3-6 % below what the same step sustains for seconds
+    # (`sustained`); settling is untimed work like the W warm-up steps, it skips nothing inside the timed region
     settle = 4
     for _ in range(settle + warmup):
         tracer.render(spp)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < settle_seconds:
+        tracer.render(spp)
+        settle += 1
     if os.environ.get("PT_BENCH_MARKER"):
         # profiling runs (tools/steady.py): one tiny, unmistakable dispatch between the untimed renders and the timed steps
         import ctypes as C
@@ -247,6 +255,7 @@ def main():
     ap.add_argument("--exchange", choices=["torch", "native"], default="torch", help="N>1: torch.distributed collectives (RCCL) or the plugin's own pt_dist_combine (RCCL)")
     ap.add_argument("--exchange-every", type=int, default=0, help="N>1: exchange after every E-th step, beside the next render; 0 = once, after the last step (inside the timed region)")
     ap.add_argument("--dump-image", default=None, help="N>1 path: rank 0 writes the combined image (float32 [pixels, 4], .npy) here after the timed region (tests)")
+    ap.add_argument("--settle-seconds", type=float, default=SETTLE_SECONDS, help="untimed renders before the timed steps until the device holds its clock (tests pass 0: they count samples)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     args = ap.parse_args()
@@ -283,7 +292,7 @@ def main():
         # ------------------------------------------------------------------ one GPU
         sequential = args.engine == "fused" and args.workload == "default"       # the reference's own streams
         m, tracer = measure(pt, args.workload, args.engine, w, h, args.steps, args.warmup, samples_per_pass=args.samples_per_pass,
-                            sequential=sequential, device=local_rank)
+                            sequential=sequential, device=local_rank, settle_seconds=args.settle_seconds)
         torch.cuda.synchronize()
         value = m["rays_per_step"] / (m["ms_per_step"] * 1e-3) / 1e6
         hbm_achieved = m["rays_per_step"] * BYTES_PER_RAY / (m["kernel_ms"] * 1e-3) / 1e9
@@ -417,6 +426,16 @@ def main():
         exchanged.record(exchange_stream)
     for k in range(4 + args.warmup):                              # 4: the plugin measures its candidates on the first renders (untimed)
         step(k)
+    # (measure(): SETTLE_SECONDS of the same steps for the clock the device holds under this load; the same COUNT on every rank --
+    # a step may hold a collective)
+    t_settle = time.perf_counter()
+    if args.settle_seconds > 0:
+        step(0)
+    torch.cuda.synchronize()
+    n_settle = torch.tensor([min(2000, int(args.settle_seconds / max(time.perf_counter() - t_settle, 1e-4)))], dtype=torch.int64, device="cuda")
+    dist.all_reduce(n_settle, op=dist.ReduceOp.MAX)
+    for _ in range(int(n_settle.item())):
+        step(0)
     exchange()                                                    # warm the collectives up too
     sync()
     st0 = tracer.stats()

@@ -275,8 +275,11 @@ __global__ void k_set_count(uint32_t* __restrict__ counts, uint32_t G, uint32_t 
 }
 
 // a5+a6. Scene triangles staged in LDS; one thread per queue entry, block-uniform loops.
+#ifndef PT_EXTEND_WAVES
+#define PT_EXTEND_WAVES 8
+#endif
 template <bool FIRST, bool BVH>
-__global__ __launch_bounds__(kBlock, 8) void k_extend(float4 origin, float4 camera, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
+__global__ __launch_bounds__(kBlock, BVH ? PT_EXTEND_WAVES : 8) void k_extend(float4 origin, float4 camera, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
                                                    const float4* __restrict__ qa, const float4* __restrict__ qb,
                                                    const uint32_t* __restrict__ count_ptr, uint32_t capacity,
                                                    uint2* __restrict__ hit, const uint32_t* __restrict__ lists, uint32_t list_pixels) {

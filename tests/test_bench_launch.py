@@ -77,7 +77,7 @@ def test_force_dist_runs_the_whole_sample_split_on_one_gpu(oracle, tmp_path, exc
     env["MASTER_ADDR"] = "127.0.0.1"
     env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = "0", "1", "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", str(steps), "--warmup", str(warmup),
-                        "--exchange", exchange, "--width", str(w), "--height", str(h), "--dump-image", str(dump)],
+                        "--exchange", exchange, "--width", str(w), "--height", str(h), "--dump-image", str(dump), "--settle-seconds", "0"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
