@@ -44,6 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))      # tests/scenes.py: the dete
 
 WIDTH, HEIGHT, SPP_PER_STEP, DEPTH = 1920, 1080, 64, 10
 SETTLE_SECONDS = 0.3          # untimed renders before the timed steps, see measure()
+PROBE_RENDERS = 12            # the plugin's own measurement: one unmeasured render, then two per candidate (at most five: pt_plugin.cpp)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles per SIMD at 2.4 GHz (same guide: v_fma_f32
 # 2 cycles on the SIMD-32; tools/valu_microbench.hip measures 2.4-2.6 at the clock the chip holds under load)
@@ -198,7 +199,7 @@ def measure(pt, workload, engine, w, h, steps, warmup, spp=SPP_PER_STEP, samples
     # ... and the device gets SETTLE_SECONDS of the same renders to reach the clock it holds under this load: the 20 steps the
     # driver times are 20 ms of work, and measured from a cold start they run 3-6 % below what the same step sustains for seconds
     # (`sustained`); settling is untimed work like the W warm-up steps, it skips nothing inside the timed region
-    settle = 4
+    settle = PROBE_RENDERS
     for _ in range(settle + warmup):
         tracer.render(spp)
     t_settle = time.perf_counter()
@@ -424,7 +425,7 @@ def main():
 
     if not native:
         exchanged.record(exchange_stream)
-    for k in range(4 + args.warmup):                              # 4: the plugin measures its candidates on the first renders (untimed)
+    for k in range(PROBE_RENDERS + args.warmup):                  # the plugin measures its candidates on the first renders (untimed)
         step(k)
     # (measure(): SETTLE_SECONDS of the same steps for the clock the device holds under this load; the same COUNT on every rank --
     # a step may hold a collective)

@@ -157,6 +157,16 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
                       const pt_material* materials, uint32_t n_materials,
                       void* host_blob, size_t blob_bytes);
 
+/* The same with the BVH decided by the caller instead of the process-wide threshold (with_bvh != 0: the blob carries one, whatever
+ * the triangle count; 0: none).  For hosts that keep BOTH forms of a small scene and measure which is faster for their way of
+ * rendering -- the plugin does, pt_plugin.h PT_BVH_DUAL_MIN_TRIANGLES: at 48 triangles the loop over all triangles from LDS wins
+ * with 64 strided samples per call (33 against 28 Grays/s) and loses 1 : 2.7 at one sample per call, the reference's frame loop. */
+size_t pt_hip_scene_blob_bytes_ex(uint32_t n_triangles, uint32_t n_materials, int with_bvh);
+int pt_hip_scene_pack_ex(const pt_vertex* vertices, uint32_t n_vertices,
+                         const pt_triangle* triangles, uint32_t n_triangles,
+                         const pt_material* materials, uint32_t n_materials,
+                         void* host_blob, size_t blob_bytes, int with_bvh);
+
 /* Exhaustive check on the device (a few ms, cached per denominator): *ok = 1 iff for every float32 a in [2^-32, denominator + 1]
  * (the numerators pixel + u that can occur)
  * the short division of PT_FRAME_FAST_DIV equals a / (float)denominator bit for bit.  Synchronises `stream`. */

@@ -84,7 +84,18 @@ typedef struct {
     uint32_t fused_out_of_step;  /* 1: the fused engine runs its out-of-step form (PT_FRAME_OUT_OF_STEP, pt_hip.h) */
     double   auto_rays_per_ms[2];/* what the probes measured, indexed by engine: [0] wavefront, [1] fused in step (0 = not probed) */
     double   fused_out_of_step_rays_per_ms;  /* ... and the fused engine out of step (scenes without a BVH) */
+    uint32_t small_scene_walks;  /* 1: a scene small enough to be looped over is rendered through its BVH (PT_BVH_DUAL_MIN_TRIANGLES) */
+    uint32_t small_scene_dual;   /* 1: the instance holds both forms of the scene and measures them against each other */
+    double   walk_rays_per_ms[2];/* ... what the probes measured for the BVH form, indexed by engine like auto_rays_per_ms */
 } pt_stats;
+
+/* Scenes of more than PT_BVH_DUAL_MIN_TRIANGLES and at most PT_BVH_DEFAULT_MIN_TRIANGLES (pt_hip.h; the process-wide threshold)
+ * triangles are packed TWICE by pt_set_scene -- for the loop over all triangles from LDS and with a BVH -- and the BVH forms of
+ * the engines join the candidates the plugin measures on the first renders (pt_options.engine): which is faster depends on how
+ * the host renders.  Measured at 48 triangles, depth 16, 1080p (profiles/r03_bvh_crossover.txt): one sample per call -- the
+ * reference's frame loop -- 7.3 Grays/s looped, 20.2 through the BVH; 16 samples per call under the reference's streams 24.6 / 28.2;
+ * 64 strided samples per call 33.3 / 28.4.  Same bits either way.  PT_SMALL_SCENE_BVH=0 in the environment: the loop only. */
+#define PT_BVH_DUAL_MIN_TRIANGLES 16u
 
 const char* pt_last_error(void);
 

@@ -33,6 +33,7 @@ PT_FRAME_OUT_OF_STEP = 4
 PT_FRAME_DEFER_FOLD = 8
 PT_MAX_DEPTH = 32
 PT_BVH_DEFAULT_MIN_TRIANGLES = 96
+PT_BVH_DUAL_MIN_TRIANGLES = 16
 PT_STATS_PUBLIC_WORDS = 64
 PT_STATS_WORDS = PT_STATS_PUBLIC_WORDS + 32 * 16
 PT_NOALLOC_SCRATCH_BYTES = 64 << 20
@@ -94,7 +95,8 @@ class Stats(C.Structure):
                 ("rays_per_bounce", C.c_uint64 * PT_MAX_DEPTH), ("last_render_ms", C.c_double),
                 ("total_render_ms", C.c_double), ("renders", C.c_uint64),
                 ("engine_in_use", C.c_uint32), ("fused_out_of_step", C.c_uint32), ("auto_rays_per_ms", C.c_double * 2),
-                ("fused_out_of_step_rays_per_ms", C.c_double)]
+                ("fused_out_of_step_rays_per_ms", C.c_double),
+                ("small_scene_walks", C.c_uint32), ("small_scene_dual", C.c_uint32), ("walk_rays_per_ms", C.c_double * 2)]
 
 
 assert C.sizeof(Vertex) == 16 and C.sizeof(Triangle) == 16 and C.sizeof(Material) == 48 and C.sizeof(CameraData) == 36
@@ -163,8 +165,10 @@ SYMBOLS = {
     "pt_hip_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
     "pt_hip_set_bvh_threshold": (C.c_int, [_U32]),
     "pt_hip_scene_blob_bytes": (_SZ, [_U32, _U32]),
+    "pt_hip_scene_blob_bytes_ex": (_SZ, [_U32, _U32, C.c_int]),
     "pt_hip_scene_has_bvh": (C.c_int, [_VP, _SZ]),
     "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
+    "pt_hip_scene_pack_ex": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ, C.c_int]),
     "pt_hip_verify_fast_div": (C.c_int, [_U32, C.POINTER(C.c_int), _VP]),
     "pt_hip_primary_lists_bytes": (_SZ, [_U32]),
     "pt_hip_build_primary_lists": (C.c_int, [C.POINTER(Frame), _VP, _U32, _U32, _VP, _VP]),

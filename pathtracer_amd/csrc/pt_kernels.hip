@@ -1096,11 +1096,14 @@ int pt_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
 
 int pt_hip_set_bvh_threshold(uint32_t min_triangles) { g_bvh_min_tris = min_triangles; return PT_OK; }
 
-size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
+size_t pt_hip_scene_blob_bytes_ex(uint32_t n_triangles, uint32_t n_materials, int with_bvh) {
 	size_t n = bvh_offset_of(n_triangles, n_materials);
-	// BVH (scenes above kBvhMinTris triangles): at most n_triangles nodes of 32 B and n_triangles leaf records of 64 B, the normal classes (kBvhClassBytes)
-	if (n_triangles > g_bvh_min_tris) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes;
+	// BVH: at most n_triangles nodes (kBvhNodeBytes each) and n_triangles leaf records of 64 B, the normal classes (kBvhClassBytes)
+	if (with_bvh && n_triangles != 0u) n += (size_t)n_triangles * (kBvhNodeBytes + 64u) + kBvhClassBytes;
 	return n;
+}
+size_t pt_hip_scene_blob_bytes(uint32_t n_triangles, uint32_t n_materials) {
+	return pt_hip_scene_blob_bytes_ex(n_triangles, n_materials, n_triangles > g_bvh_min_tris);      // scenes above the threshold carry a BVH
 }
 
 int pt_hip_scene_has_bvh(const void* host_blob, size_t blob_bytes) {
@@ -1115,12 +1118,21 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
                       const pt_triangle* triangles, uint32_t n_triangles,
                       const pt_material* materials, uint32_t n_materials,
                       void* host_blob, size_t blob_bytes) {
+	return pt_hip_scene_pack_ex(vertices, n_vertices, triangles, n_triangles, materials, n_materials, host_blob, blob_bytes, n_triangles > g_bvh_min_tris);
+}
+
+int pt_hip_scene_pack_ex(const pt_vertex* vertices, uint32_t n_vertices,
+                         const pt_triangle* triangles, uint32_t n_triangles,
+                         const pt_material* materials, uint32_t n_materials,
+                         void* host_blob, size_t blob_bytes, int with_bvh) {
 	if ((!vertices && n_vertices) || (!triangles && n_triangles) || (!materials && n_materials) || !host_blob)
 		return fail(PT_ERR_INVALID, "scene_pack: null pointer");
-	if (blob_bytes < pt_hip_scene_blob_bytes(n_triangles, n_materials)) return fail(PT_ERR_NOMEM, "scene_pack: blob too small");
+	with_bvh = with_bvh && n_triangles != 0u;
+	const size_t need_bytes = pt_hip_scene_blob_bytes_ex(n_triangles, n_materials, with_bvh);
+	if (blob_bytes < need_bytes) return fail(PT_ERR_NOMEM, "scene_pack: blob too small");
 	if (n_triangles > (1u << 26)) return fail(PT_ERR_LIMIT, "scene_pack: more than 2^26 triangles");
 	unsigned char* base = (unsigned char*)host_blob;
-	if (pt_hip_scene_blob_bytes(n_triangles, n_materials) > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "scene_pack: blob larger than 4 GiB");
+	if (need_bytes > 0xFFFFFFFFull) return fail(PT_ERR_LIMIT, "scene_pack: blob larger than 4 GiB");
 	for (uint32_t k = 0; k < n_triangles; k++) {
 		const pt_triangle& t = triangles[k];
 		if (t.vertexIdx0 >= n_vertices || t.vertexIdx1 >= n_vertices || t.vertexIdx2 >= n_vertices)
@@ -1128,18 +1140,18 @@ int pt_hip_scene_pack(const pt_vertex* vertices, uint32_t n_vertices,
 		if (t.materialIdx >= n_materials)
 			return fail(PT_ERR_INVALID, "scene_pack: triangle " + std::to_string(k) + " has a material index out of range");
 	}
-	std::memset(base, 0, pt_hip_scene_blob_bytes(n_triangles, n_materials));
+	std::memset(base, 0, need_bytes);
 	SceneHeader hdr{};
 	hdr.n_tris = n_triangles; hdr.n_mats = n_materials;
 	hdr.tri_offset = (uint32_t)sizeof(SceneHeader);
 	hdr.mat_offset = hdr.tri_offset + n_triangles * (uint32_t)sizeof(TriRec);
 	hdr.magic = kSceneMagic;
-	hdr.blob_bytes = (uint32_t)pt_hip_scene_blob_bytes(n_triangles, n_materials);
+	hdr.blob_bytes = (uint32_t)need_bytes;
 	hdr.bvh_offset = bvh_offset_of(n_triangles, n_materials);
 	hdr.leaf_offset = hdr.bvh_offset + n_triangles * kBvhNodeBytes;
 	{
 		// bounding sphere + (large scenes) the BVH: see pt_bvh.hpp for why the result stays the brute-force one
-		if (n_triangles > g_bvh_min_tris) {
+		if (with_bvh) {
 			ptbvh::Built bvh = ptbvh::build(vertices, triangles, n_triangles, bvh_depth_budget(n_triangles));
 			if (bvh.nodes.size() > n_triangles || bvh.nodes4.size() > n_triangles) return fail(PT_ERR_LIMIT, "scene_pack: BVH larger than its reservation");
 			// (two trees: the marker that leads from the first to the second takes one level of the stack under the first one's walk)

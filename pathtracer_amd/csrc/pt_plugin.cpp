@@ -92,6 +92,7 @@ class PathTracer final : public IPathTracer {
 		uint32_t* rng = nullptr;        // per-pixel xorshift32 stream (RngState, Structures.cuh:18)
 		void* mean = nullptr;           // float4 running mean(s): stands in for the GL surface
 		void* scene = nullptr;          // packed Triangle/Vertex/Material blob
+		void* scene_walk = nullptr;     // small scenes held in both forms (_sceneDual): the same scene packed with a BVH
 		uint64_t* stats = nullptr;
 		void* workspace = nullptr;      // wavefront queues
 		void* image = nullptr;          // SAMPLE split: the combined image, _pitch float4
@@ -106,6 +107,7 @@ class PathTracer final : public IPathTracer {
 	size_t _workspaceBytes = 0, _stackedBytes = 0;
 	uint32_t _nTris = 0, _nMats = 0;
 	bool _sceneHasBvh = false;          // recorded when the scene is packed (pt_hip_scene_has_bvh), passed with every frame
+	bool _sceneDual = false;            // a small scene held in both forms: _dev.scene loops over all triangles, _dev.scene_walk carries a BVH (pt_plugin.h)
 	uint64_t _sceneHash = 0;            // FNV-1a of the packed blob: a state file is only resumed on the scene it was saved on
 	int _device = -1;                   // resolved HIP ordinal of this instance, bound by every method (DeviceScope)
 	void* _stream = nullptr;
@@ -133,12 +135,17 @@ class PathTracer final : public IPathTracer {
 	// from then on the one that traced most rays per millisecond of device time (HIP events, device ray counters).  Candidates: PT_ENGINE_AUTO -- fused in step, fused out of step (pt_hip.h
 	// PT_FRAME_OUT_OF_STEP; scenes without a BVH), wavefront; PT_ENGINE_FUSED -- its two forms; PT_ENGINE_WAVEFRONT -- none.
 	// A camera restart keeps the decision.
-	enum Candidate : uint32_t { CandWavefront = 0, CandFused = 1, CandFusedOutOfStep = 2, kCandidates = 3 };
-	uint32_t _cands[kCandidates] = { CandFused, CandFused, CandFused };
+	// Small scenes held in both forms (_sceneDual) add the engines' BVH forms: CandWavefrontWalk, CandFusedWalk.
+	enum Candidate : uint32_t { CandWavefront = 0, CandFused = 1, CandFusedOutOfStep = 2, CandWavefrontWalk = 3, CandFusedWalk = 4, kCandidates = 5 };
+	uint32_t _cands[kCandidates] = { CandFused, CandFused, CandFused, CandFused, CandFused };
+	static bool _IsWavefront(uint32_t c) { return c == CandWavefront || c == CandWavefrontWalk; }
+	static bool _IsWalk(uint32_t c) { return c == CandWavefrontWalk || c == CandFusedWalk; }
 	uint32_t _nCands = 1, _probeIdx = 0;        // probing while _probeIdx < _nCands (and _nCands > 1)
+	static constexpr uint32_t kProbeRenders = 2;
+	uint32_t _probeRep = 0;                     // renders the candidate under measurement has had
 	bool _probeWarm = false;                    // the first render after a (re)start has run: it is not measured (cold caches, first touch of fresh buffers)
 	uint32_t _choice = CandFused, _candInFlight = CandFused;
-	double _candRate[kCandidates] = { 0.0, 0.0, 0.0 };     // rays per ms
+	double _candRate[kCandidates] = { 0.0, 0.0, 0.0, 0.0, 0.0 };     // rays per ms
 	bool Probing() const { return _nCands > 1 && _probeIdx < _nCands; }
 	// A decision is kept per (scene, image size, pixel range, options, class of samples per call) for the life of the instance: a host
 	// that alternates between one sample per call while the camera moves and 64 when it rests, or resizes back to a size it
@@ -165,13 +172,18 @@ class PathTracer final : public IPathTracer {
 		                 _opt.depth, _opt.shading, _opt.split_mode, _opt.split_rank, _opt.split_ranks, _opt.virtual_shards, _opt.samples_per_pass, bucket };
 	}
 	void _ResetProbe() {
-		_nCands = 0; _probeIdx = 0; _probedSamples = 0; _probeWarm = false; _bucket = kNoBucket;
+		_nCands = 0; _probeIdx = 0; _probeRep = 0; _probedSamples = 0; _probeWarm = false; _bucket = kNoBucket;
 		for (double& r : _candRate) r = 0.0;
-		if (_opt.engine == PT_ENGINE_WAVEFRONT) _cands[_nCands++] = CandWavefront;
-		else {
+		// (PT_FUSED_OUT_OF_STEP in the environment forces that form of the loop, a measurement knob: the BVH forms stay out of its way)
+		const bool walks = _sceneDual && !std::getenv("PT_FUSED_OUT_OF_STEP");
+		if (_opt.engine == PT_ENGINE_WAVEFRONT) {
+			_cands[_nCands++] = CandWavefront;
+			if (walks) _cands[_nCands++] = CandWavefrontWalk;
+		} else {
 			_cands[_nCands++] = CandFused;
 			if (!_sceneHasBvh) _cands[_nCands++] = CandFusedOutOfStep;
-			if (_opt.engine == PT_ENGINE_AUTO) _cands[_nCands++] = CandWavefront;
+			if (walks) _cands[_nCands++] = CandFusedWalk;
+			if (_opt.engine == PT_ENGINE_AUTO) { _cands[_nCands++] = CandWavefront; if (walks) _cands[_nCands++] = CandWavefrontWalk; }
 		}
 		_choice = _cands[0];
 	}
@@ -221,7 +233,7 @@ public:
 		if (_drawState == Drawing) FinalizeDrawing();
 		if (_stream) pt_hip_stream_synchronize(_stream);
 		if (_comm) pt_hip_comm_destroy(_comm);
-		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.scene);
+		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.scene); pt_hip_free(_dev.scene_walk);
 		pt_hip_free(_dev.stats); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked); pt_hip_free(_dev.lists);
 		pt_hip_event_destroy(_evStart); pt_hip_event_destroy(_evStop);
 		for (uint32_t k = 0; k < kSideStreams; k++) {
@@ -361,8 +373,21 @@ public:
 		PT_TRY(pt_hip_malloc(&fresh, bytes));
 		if (int rc = pt_hip_memcpy_h2d(fresh, blob.data(), bytes, _stream)) { pt_hip_free(fresh); return hip_layer_fail(rc, "scene upload"); }
 		PT_TRY(pt_hip_stream_synchronize(_stream));
-		pt_hip_free(_dev.scene);
-		_dev.scene = fresh; _nTris = nt; _nMats = nm; _sceneHasBvh = has_bvh != 0;
+		// a small scene also in its BVH form (pt_plugin.h, PT_BVH_DUAL_MIN_TRIANGLES): the candidates that walk it render from this blob
+		void* fresh_walk = nullptr;
+		const char* dual_env = std::getenv("PT_SMALL_SCENE_BVH");
+		if (!has_bvh && nt > PT_BVH_DUAL_MIN_TRIANGLES && !(dual_env && dual_env[0] == '0')) {
+			size_t wbytes = pt_hip_scene_blob_bytes_ex(nt, nm, 1);
+			std::vector<unsigned char> wblob(wbytes);
+			int rc = pt_hip_scene_pack_ex(v, nv, t, nt, m, nm, wblob.data(), wbytes, 1);
+			if (rc == PT_OK) rc = pt_hip_malloc(&fresh_walk, wbytes);
+			if (rc == PT_OK) rc = pt_hip_memcpy_h2d(fresh_walk, wblob.data(), wbytes, _stream);
+			if (rc == PT_OK) rc = pt_hip_stream_synchronize(_stream);
+			if (rc != PT_OK) { pt_hip_free(fresh_walk); pt_hip_free(fresh); return hip_layer_fail(rc, "scene upload (BVH form)"); }
+		}
+		pt_hip_free(_dev.scene); pt_hip_free(_dev.scene_walk);
+		_dev.scene = fresh; _dev.scene_walk = fresh_walk; _sceneDual = fresh_walk != nullptr;
+		_nTris = nt; _nMats = nm; _sceneHasBvh = has_bvh != 0;
 		_sceneHash = 1469598103934665603ull;
 		for (unsigned char c : blob) _sceneHash = (_sceneHash ^ c) * 1099511628211ull;
 		_ResetProbe();
@@ -449,7 +474,10 @@ public:
 		out->frames = _frameNumber;
 		for (int b = 0; b < PT_MAX_DEPTH; b++) out->rays_per_bounce[b] = words[4 + b];
 		out->last_render_ms = _lastMs; out->total_render_ms = _totalMs; out->renders = _renders;
-		out->engine_in_use = _opt.engine != PT_ENGINE_AUTO ? _opt.engine : Probing() ? (uint32_t)PT_ENGINE_AUTO : _choice == CandWavefront ? (uint32_t)PT_ENGINE_WAVEFRONT : (uint32_t)PT_ENGINE_FUSED;
+		out->engine_in_use = _opt.engine != PT_ENGINE_AUTO ? _opt.engine : Probing() ? (uint32_t)PT_ENGINE_AUTO : _IsWavefront(_choice) ? (uint32_t)PT_ENGINE_WAVEFRONT : (uint32_t)PT_ENGINE_FUSED;
+		out->small_scene_dual = _sceneDual ? 1u : 0u;
+		out->small_scene_walks = !Probing() && _IsWalk(_choice) ? 1u : 0u;
+		out->walk_rays_per_ms[0] = _candRate[CandWavefrontWalk]; out->walk_rays_per_ms[1] = _candRate[CandFusedWalk];
 		out->fused_out_of_step = !Probing() && _choice == CandFusedOutOfStep ? 1u : 0u;
 		out->auto_rays_per_ms[0] = _candRate[CandWavefront]; out->auto_rays_per_ms[1] = _candRate[CandFused];
 		out->fused_out_of_step_rays_per_ms = _candRate[CandFusedOutOfStep];
@@ -712,14 +740,19 @@ private:
 		uint64_t rays = 0;
 		if (int rc = _ReadRays(&rays)) return rc;
 		if (!_probeWarm) { _probeWarm = true; return PT_OK; }       // the very first render only warms the device up: the first candidate runs again
-		_candRate[_candInFlight] = ms > 0.0f ? (double)(rays - _raysBefore) / ms : 0.0;
+		// every candidate renders kProbeRenders times and keeps its best: a kernel's first launch (its code goes to the device) and a
+		// render of a tenth of a millisecond measured once made the choice a matter of luck at one sample per call
+		const double rate = ms > 0.0f ? (double)(rays - _raysBefore) / ms : 0.0;
+		if (rate > _candRate[_candInFlight]) _candRate[_candInFlight] = rate;
+		if (++_probeRep < kProbeRenders) return PT_OK;
+		_probeRep = 0;
 		if (++_probeIdx < _nCands) return PT_OK;
 		_choice = _cands[0];
 		for (uint32_t k = 1; k < _nCands; k++)
 			if (_candRate[_cands[k]] > _candRate[_choice]) _choice = _cands[k];
 		// (the wavefront workspace stays once it has been allocated: another class of samples per call may want it, and it goes with
 		// the buffers on an options or size change)
-		ProbeEntry e{ _KeyNow(_bucket), _choice, { _candRate[0], _candRate[1], _candRate[2] } };
+		ProbeEntry e{ _KeyNow(_bucket), _choice, { _candRate[0], _candRate[1], _candRate[2], _candRate[3], _candRate[4] } };
 		bool known = false;
 		for (ProbeEntry& d : _decided) if (d.key == e.key) { d = e; known = true; }
 		if (!known) _decided.push_back(e);
@@ -730,8 +763,9 @@ private:
 		if (!Probing()) return _choice;
 		uint32_t c = _cands[_probeIdx];
 		// the wavefront probe needs its queues; if they cannot be had under AUTO it leaves the list (it is the last entry)
-		if (c == CandWavefront && _opt.engine == PT_ENGINE_AUTO && _EnsureWorkspace() != PT_OK) {
-			_nCands--;
+		if (_IsWavefront(c) && _opt.engine == PT_ENGINE_AUTO && _EnsureWorkspace() != PT_OK) {
+			// (the wavefront candidates close the list: its loop form, then -- small scenes in both forms -- its BVH form)
+			_nCands = _probeIdx;
 			if (!Probing()) {
 				_choice = _cands[0];
 				for (uint32_t k = 1; k < _nCands; k++)
@@ -760,28 +794,38 @@ private:
 				_choice = seen->choice; _probeIdx = _nCands;
 				for (uint32_t k = 0; k < kCandidates; k++) _candRate[k] = seen->rate[k];
 			} else {
-				_probeIdx = 0;
+				_probeIdx = 0; _probeRep = 0;
 				for (double& r : _candRate) r = 0.0;
 			}
 		}
 		if (Probing() && _probeIdx == 0) _probedSamples = samples;
 		uint32_t cand = _PickCandidate();
-		if (cand == CandWavefront && _opt.engine == PT_ENGINE_AUTO && _EnsureWorkspace() != PT_OK) cand = CandFused;      // a remembered choice whose queues cannot be had any more
-		const uint32_t engine = cand == CandWavefront ? (uint32_t)PT_ENGINE_WAVEFRONT : (uint32_t)PT_ENGINE_FUSED;
+		if (_IsWavefront(cand) && _opt.engine == PT_ENGINE_AUTO && _EnsureWorkspace() != PT_OK) cand = _IsWalk(cand) ? CandFusedWalk : CandFused;      // a remembered choice whose queues cannot be had any more
+		const uint32_t engine = _IsWavefront(cand) ? (uint32_t)PT_ENGINE_WAVEFRONT : (uint32_t)PT_ENGINE_FUSED;
 		if (cand == CandFusedOutOfStep) f.flags |= PT_FRAME_OUT_OF_STEP;
+		// which form of the scene this render takes: a small scene's BVH form lives in a blob of its own
+		const bool walk = _sceneHasBvh || (_sceneDual && _IsWalk(cand));
+		void* const scene = _sceneDual && _IsWalk(cand) ? _dev.scene_walk : _dev.scene;
+		if (walk) f.flags |= PT_FRAME_SCENE_BVH;
+		f.primary_lists = walk && _listsValid ? (uint64_t)(uintptr_t)_dev.lists : 0ull;
 		if (Probing()) {
 			if (int rc = _ReadRays(&_raysBefore)) return rc;          // (waits for what is on the stream: probes only)
 		}
 		_candInFlight = cand;
 		_imageCurrent = false;
-		PT_TRY(pt_hip_event_record(_evStart, _stream));
-		if (_sceneHasBvh && !_listsValid && (uint64_t)_frameNumber + samples >= kListsFromSample && !std::getenv("PT_PRIMARY_LISTS")) {
-			// (inside the timed region: the device time the statistics report includes it)
+		// (inside the timed region: the device time the statistics report includes it -- except under a probe, where the one walk per
+		// pixel would be charged to whichever BVH candidate happens to run first)
+		const bool lists_now = walk && !_listsValid && (uint64_t)_frameNumber + samples >= kListsFromSample && !std::getenv("PT_PRIMARY_LISTS");
+		auto build_lists = [&]() -> int {
 			if (!_dev.lists) PT_TRY(pt_hip_malloc(&_dev.lists, pt_hip_primary_lists_bytes(_pixelCount)));
-			PT_TRY(pt_hip_build_primary_lists(&f, _dev.scene, _nTris, _nMats, _dev.lists, _stream));
+			PT_TRY(pt_hip_build_primary_lists(&f, scene, _nTris, _nMats, _dev.lists, _stream));
 			_listsValid = true;
 			f.primary_lists = (uint64_t)(uintptr_t)_dev.lists;
-		}
+			return PT_OK;
+		};
+		if (lists_now && Probing()) { if (int rc = build_lists()) return rc; }
+		PT_TRY(pt_hip_event_record(_evStart, _stream));
+		if (lists_now && !_listsValid) { if (int rc = build_lists()) return rc; }
 		// Several local shards through the fused engine (strided streams: the stream words are only READ, and each shard
 		// writes a mean of its own).  Brute-force scenes in step: all of them in ONE launch (pt_hip_render_fused_shards) --
 		// a launch per shard costs 0.06 ms of a 1.0 ms step (tools/split_cost.py, 1080p, 8 shards x 8 samples).
@@ -790,7 +834,7 @@ private:
 		if (one_launch) {
 			uint32_t firsts[PT_FUSED_MAX_SHARDS];
 			for (uint32_t j = 0; j < _localShards; j++) firsts[j] = _opt.sample_offset + (_opt.split_rank + j * _ranks) * PT_SHARD_SPAN + _frameNumber;
-			PT_TRY(pt_hip_render_fused_shards(&f, _dev.scene, _nTris, _nMats, firsts, _localShards, _frameNumber, samples, _dev.rng, _dev.mean, _pitch, _dev.stats, _stream));
+			PT_TRY(pt_hip_render_fused_shards(&f, scene, _nTris, _nMats, firsts, _localShards, _frameNumber, samples, _dev.rng, _dev.mean, _pitch, _dev.stats, _stream));
 			PT_TRY(pt_hip_event_record(_evStop, _stream));
 			_inFlightSamples = samples;
 			return PT_OK;
@@ -813,10 +857,10 @@ private:
 			void* mean = (char*)_dev.mean + (size_t)j * _pitch * 16;
 			void* stream = spread && j % (kSideStreams + 1u) != 0u ? _side[j % (kSideStreams + 1u) - 1u] : _stream;
 			if (engine == PT_ENGINE_WAVEFRONT) {
-				PT_TRY(pt_hip_render_wavefront(&f, _dev.scene, _nTris, _nMats, frame_first, _frameNumber, samples, _opt.samples_per_pass,
+				PT_TRY(pt_hip_render_wavefront(&f, scene, _nTris, _nMats, frame_first, _frameNumber, samples, _opt.samples_per_pass,
 				                               _dev.rng, mean, _dev.workspace, _workspaceBytes, _dev.stats, _stream));
 			} else {
-				PT_TRY(pt_hip_render_fused(&f, _dev.scene, _nTris, _nMats, frame_first, _frameNumber, samples,
+				PT_TRY(pt_hip_render_fused(&f, scene, _nTris, _nMats, frame_first, _frameNumber, samples,
 				                           _dev.rng, mean, _dev.stats, stream));
 			}
 		}

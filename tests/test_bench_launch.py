@@ -88,8 +88,8 @@ def test_force_dist_runs_the_whole_sample_split_on_one_gpu(oracle, tmp_path, exc
     assert out["value"] > 0 and out["render_ms_max"] > 0 and out["exchange_ms"] >= 0 and out["render_ms_min"] <= out["render_ms_max"]
     assert abs(out["render_ms_max"] + out["exchange_ms"] - out["ms_per_step"] * steps) < 1e-2 * out["ms_per_step"] * steps + 0.05
     assert ("pt_dist_combine" if exchange == "native" else "torch.distributed") in out["config"]["parallelism"]
-    # the image: 8 virtual shards, each (4 settle + warmup + steps) x 8 samples, combined by the fixed-order tree
-    per_shard = (4 + warmup + steps) * (64 // 8)
+    # the image: 8 virtual shards, each (12 probe renders + warmup + steps) x 8 samples, combined by the fixed-order tree
+    per_shard = (12 + warmup + steps) * (64 // 8)
     want, _ = oracle.render_sharded(oracle.params(w, h, rng_mode=oracle.RNG_STRIDED, stride=35, spp=per_shard * 8), 8, span=1 << 20)
     got = np.load(dump)
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -158,20 +158,24 @@ def test_cpp_multi_gpu_host(pt, oracle, tmp_path, instances, mode):
 @pytest.mark.parametrize("scene_name", ["default", "materials", "synthetic2500"])
 def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
     """PT_ENGINE_AUTO (the default): the first renders measure one candidate each -- fused in step, fused out of step (scenes
-    without a BVH), wavefront -- then the fastest stays; the image is the oracle's whichever runs, and a camera restart keeps
-    the decision"""
+    without a BVH), wavefront, and for a small scene the plugin holds in both forms (more than PT_BVH_DUAL_MIN_TRIANGLES triangles, no
+    BVH by the threshold: the 48-triangle all-materials scene) the two engines through the BVH as well -- then the fastest stays; the
+    image is the oracle's whichever runs, and a camera restart keeps the decision"""
     V, T, M = {"default": scenes.default_scene, "materials": scenes.all_materials_scene, "synthetic2500": lambda: scenes.synthetic_scene(2500)}[scene_name]()
     w, h = 200, 120
-    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=7), scene=oracle.make_scene(V, T, M))
     has_bvh = len(T) > pt.PT_BVH_DEFAULT_MIN_TRIANGLES
+    dual = not has_bvh and len(T) > pt.PT_BVH_DUAL_MIN_TRIANGLES
+    # one unmeasured render (a cold device would count against whoever goes first), then two renders per candidate (the better one
+    # counts): BVH scenes have 2 candidates, small scenes held in both forms 5, the rest 3
+    n_probe = 1 + 2 * (2 if has_bvh else 5 if dual else 3)
+    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=n_probe + 1), scene=oracle.make_scene(V, T, M))
     with pt.PathTracer(w, h) as tr:
         assert tr.get_options().engine == pt.PT_ENGINE_AUTO
         tr.set_scene(*pt.make_scene(V, T, M))
-        assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO
-        # one unmeasured render (a cold device would count against whoever goes first), then one render per candidate
-        for spp in ([2, 2, 2] if has_bvh else [2, 2, 1, 1]):
+        assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO and tr.stats().small_scene_dual == (1 if dual else 0)
+        for _ in range(n_probe):
             assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO          # still measuring
-            tr.render(spp)
+            tr.render(1)
         st = tr.stats()
         assert st.engine_in_use in (pt.PT_ENGINE_FUSED, pt.PT_ENGINE_WAVEFRONT)
         rates = {"wavefront": st.auto_rays_per_ms[0], "fused": st.auto_rays_per_ms[1]}
@@ -179,10 +183,15 @@ def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
             rates["fused out of step"] = st.fused_out_of_step_rays_per_ms
         else:
             assert st.fused_out_of_step_rays_per_ms == 0 and st.fused_out_of_step == 0
+        if dual:
+            rates["wavefront, BVH"], rates["fused, BVH"] = st.walk_rays_per_ms[0], st.walk_rays_per_ms[1]
+        else:
+            assert st.walk_rays_per_ms[0] == 0 and st.walk_rays_per_ms[1] == 0 and st.small_scene_walks == 0
         assert all(v > 0 for v in rates.values()), rates
         best = max(rates, key=rates.get)
-        assert st.engine_in_use == (pt.PT_ENGINE_WAVEFRONT if best == "wavefront" else pt.PT_ENGINE_FUSED)
+        assert st.engine_in_use == (pt.PT_ENGINE_WAVEFRONT if best.startswith("wavefront") else pt.PT_ENGINE_FUSED)
         assert st.fused_out_of_step == (1 if best == "fused out of step" else 0)
+        assert st.small_scene_walks == (1 if best.endswith("BVH") else 0)
         tr.render(1)
         img, rng, st = tr.readback(), tr.readback_rng(), tr.stats()
         assert_bit_equal(img, ref, f"auto on {scene_name}")
@@ -204,19 +213,24 @@ def test_candidates_are_measured_again_when_the_samples_per_call_change(pt, orac
     with pt.PathTracer(w, h) as tr:
         tr.set_scene(*pt.make_scene(V, T, M))
         tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=12)
-        for _ in range(3):
+        for _ in range(7):                                 # one unmeasured render, then two per form
             tr.render(1)
         first = tr.stats()
-        assert first.auto_rays_per_ms[1] > 0 and first.fused_out_of_step_rays_per_ms > 0       # both forms measured at 1 sample per call
+        # every form measured at 1 sample per call: in step, out of step, and -- 48 triangles: the plugin holds the scene in both forms -- through the BVH
+        assert first.auto_rays_per_ms[1] > 0 and first.fused_out_of_step_rays_per_ms > 0 and first.walk_rays_per_ms[1] > 0 and first.small_scene_dual == 1
         tr.render(2)                                       # not a fourfold change: nothing is measured again
         assert tr.stats().auto_rays_per_ms[1] == first.auto_rays_per_ms[1]
-        tr.render(16)                                      # measured again: in step first ...
+        tr.render(16); tr.render(16)                       # measured again: in step first ...
         mid = tr.stats()
         assert mid.auto_rays_per_ms[1] != first.auto_rays_per_ms[1] and mid.fused_out_of_step_rays_per_ms == 0
-        tr.render(16)                                      # ... then out of step
+        tr.render(16); tr.render(16)                       # ... then out of step ...
+        assert tr.stats().fused_out_of_step_rays_per_ms > 0 and tr.stats().walk_rays_per_ms[1] == 0
+        tr.render(16); tr.render(16)                       # ... then through the BVH
         last = tr.stats()
-        assert last.fused_out_of_step_rays_per_ms > 0
-        assert last.fused_out_of_step == (1 if last.fused_out_of_step_rays_per_ms > last.auto_rays_per_ms[1] else 0)
+        assert last.walk_rays_per_ms[1] > 0
+        best = max(last.auto_rays_per_ms[1], last.fused_out_of_step_rays_per_ms, last.walk_rays_per_ms[1])
+        assert last.fused_out_of_step == (1 if last.fused_out_of_step_rays_per_ms == best else 0)
+        assert last.small_scene_walks == (1 if last.walk_rays_per_ms[1] == best else 0)
         # back to one sample per call: that class has been decided before and is NOT measured again (a host that alternates between
         # 1 sample while the camera moves and 16 when it rests pays for each class once) -- the remembered rates and choice return
         tr.render(1)
@@ -233,10 +247,10 @@ def test_candidates_are_measured_again_when_the_samples_per_call_change(pt, orac
         back = tr.stats()
         assert back.frames == 1 and back.auto_rays_per_ms[1] == first.auto_rays_per_ms[1] and back.fused_out_of_step == first.fused_out_of_step
         tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=12)          # restart for the image check below
-        for spp_ in (1, 1, 1, 2, 16, 16):
+        for spp_ in (1, 1, 1, 1, 2, 16, 16, 16):
             tr.render(spp_)
         img = tr.readback()
-    ref, _, _, _ = oracle.render(oracle.params(w, h, depth=12, spp=3 + 2 + 32), scene=oracle.make_scene(V, T, M))
+    ref, _, _, _ = oracle.render(oracle.params(w, h, depth=12, spp=4 + 2 + 48), scene=oracle.make_scene(V, T, M))
     assert_bit_equal(img, ref, "all materials, fused engine across two measurements")
 
 

@@ -31,7 +31,8 @@ def run(name, scene, w, h, spp, depth, engine, check_pixels=2000, samples_per_pa
         tr.set_options(engine=pt.PT_ENGINE_WAVEFRONT if engine == "wavefront" else pt.PT_ENGINE_FUSED, depth=depth,
                        samples_per_pass=samples_per_pass, shading=shading,
                        rng_mode=pt.PT_RNG_STRIDED if strided else pt.PT_RNG_SEQUENTIAL, stride=stride)
-        tr.render(1)                    # warm-up (also restarts below)
+        for _ in range(12):             # warm-up, and the plugin's measurement of its candidates (decisions survive the restart below)
+            tr.render(spp)
         tr.set_options(depth=depth)     # restart accumulation
         t0 = time.perf_counter()
         tr.render(spp)

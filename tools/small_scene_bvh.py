@@ -20,7 +20,7 @@ depth = 16
 with pt.PathTracer(1920, 1080) as tr:
     tr.set_scene(*pt.make_scene(*scenes.all_materials_scene()))
     tr.set_options(engine=engine, depth=depth, samples_per_pass=16, rng_mode=pt.PT_RNG_STRIDED, stride=2 + 33 * depth)
-    for _ in range(5):
+    for _ in range(12):
         tr.render(64)
     s0 = tr.stats()
     for _ in range(renders):
