@@ -806,7 +806,13 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 #define PT_FUSED_BVH_WAVES 5
 #endif
 
-template <bool STRIDED>
+// LDS_TREE: the whole tree -- nodes and leaf records, at most kLdsTreeBytesPerTriangle per triangle -- is copied into the block's LDS behind
+// the stack and walked from there (small scenes: the plugin's BVH form of a scene it also loops over, pt_plugin.h)
+constexpr uint32_t kLdsTreeBytesPerTriangle = kBvhNodeBytes + 64u;
+#ifndef PT_LDS_TREE_MAX_TRIANGLES
+#define PT_LDS_TREE_MAX_TRIANGLES 128u
+#endif
+template <bool STRIDED, bool LDS_TREE>
 __global__ __launch_bounds__(kBlock, PT_FUSED_BVH_WAVES) void k_fused_bvh(FrameDev f, const unsigned char* __restrict__ scene,
                                                       uint32_t n_tris, uint32_t n_mats, JumpMat first, JumpMat per_sample,
                                                       uint32_t mean_first, uint32_t n_samples, uint32_t range,
@@ -823,7 +829,17 @@ __global__ __launch_bounds__(kBlock, PT_FUSED_BVH_WAVES) void k_fused_bvh(FrameD
 	if (threadIdx.x == 0) s_next = 0;
 	stage_jump31(s_jump);
 	const float4* tris = reinterpret_cast<const float4*>(scene + sizeof(SceneHeader));
-	FusedBvhCtx c{ f, make_bvh_view(scene, n_tris, n_mats, f.origin), tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_stride,
+	BvhView bv = make_bvh_view(scene, n_tris, n_mats, f.origin);
+	if (LDS_TREE) {
+		float4* s_tree = s_dyn + (size_t)bvh_stack_depth(n_tris) * (kBlock / 4);       // behind the stack's bvh_stack_depth x 256 words
+		const uint32_t node_vecs = bv.n_nodes * (kBvhNodeBytes / 16u), leaf_vecs = n_tris * 4u;
+		const float4* g_nodes = reinterpret_cast<const float4*>(bv.nodes);
+		for (uint32_t k = threadIdx.x; k < node_vecs; k += kBlock) s_tree[k] = g_nodes[k];
+		for (uint32_t k = threadIdx.x; k < leaf_vecs; k += kBlock) s_tree[node_vecs + k] = bv.leaves[k];
+		bv.nodes = reinterpret_cast<const uint4*>(s_tree);
+		bv.leaves = s_tree + node_vecs;
+	}
+	FusedBvhCtx c{ f, bv, tris, tris + (size_t)n_tris * 4, s_jump, s_first, s_stride,
 	               mean_first, n_samples, rng_io, mean_io };
 	__syncthreads();
 	uint32_t n_rays = 0, n_diffuse = 0;
@@ -1593,9 +1609,12 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 		const uint32_t resident = (uint32_t)grid_for((size_t)1 << 40) / 8u * (uint32_t)PT_FUSED_BVH_WAVES;      // CUs x blocks per CU
 		dim3 pgrid(range ? (unsigned)(((size_t)frame->pixel_count + range - 1) / range)
 		                 : (unsigned)std::max<size_t>(1, std::min<size_t>(resident, ((size_t)frame->pixel_count + kBlock - 1) / kBlock)));
-#define PT_FUSED_BVH(STR) hipLaunchKernelGGL((k_fused_bvh<STR>), pgrid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
+		const bool lds_tree = si.n_tris <= PT_LDS_TREE_MAX_TRIANGLES && !std::getenv("PT_LDS_TREE_OFF");
+		const size_t lds_fused = lds_bytes + (lds_tree ? (size_t)si.n_tris * kLdsTreeBytesPerTriangle : 0);
+#define PT_FUSED_BVH(STR, TREE) hipLaunchKernelGGL((k_fused_bvh<STR, TREE>), pgrid, block, lds_fused, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, range, rng, (float4*)mean, (unsigned long long*)stats)
-		if (strided) PT_FUSED_BVH(true); else PT_FUSED_BVH(false);
+		if (lds_tree) { if (strided) PT_FUSED_BVH(true, true); else PT_FUSED_BVH(false, true); }
+		else { if (strided) PT_FUSED_BVH(true, false); else PT_FUSED_BVH(false, false); }
 #undef PT_FUSED_BVH
 	}
 	else if (mode != 2 && ((frame->flags & PT_FRAME_OUT_OF_STEP) || std::getenv("PT_FUSED_OUT_OF_STEP"))) {      // (the environment: measurement knob)

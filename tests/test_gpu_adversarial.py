@@ -64,3 +64,37 @@ def test_heap_of_large_triangles_fills_the_traversal_stack(pt, oracle, name, eng
     diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
     assert not diff.any(), f"{name}: {int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
     assert got.rays == st.rays and st.rays > w * h * spp
+
+
+@pytest.mark.parametrize("scene_name,depth,strided", [("materials", 16, False), ("materials", 16, True), ("synthetic108", 10, False), ("soup40", 8, True)])
+def test_small_trees_walked_from_lds(pt, oracle, scene_name, depth, strided):
+    """Scenes of up to 128 triangles that carry a BVH -- the plugin's BVH form of a small scene (17..96 triangles, pt_plugin.h) and scenes just
+    above the threshold -- are walked by the fused engine from a copy of the whole tree in LDS (k_fused_bvh<*, true>); PT_LDS_TREE_OFF in
+    the environment keeps the walk in global memory.  Both against the oracle, every pixel, and the streams' last words."""
+    import os
+    import scenes
+    V, T, M = {"materials": scenes.all_materials_scene, "synthetic108": lambda: scenes.synthetic_scene(108), "soup40": lambda: scenes.triangle_soup(40, 5)}[scene_name]()
+    w, h, spp = 160, 90, 3
+    mode = dict(rng_mode=oracle.RNG_STRIDED, stride=2 + 33 * depth) if strided else {}
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, **mode), scene=oracle.make_scene(V, T, M))
+    lib = pt.load_library()
+    lib.pt_hip_set_bvh_threshold(16)                        # every scene here is packed with a BVH
+    try:
+        for off in (False, True):
+            if off:
+                os.environ["PT_LDS_TREE_OFF"] = "1"
+            try:
+                with pt.PathTracer(w, h) as tr:
+                    tr.set_scene(*pt.make_scene(V, T, M))
+                    kw = dict(rng_mode=pt.PT_RNG_STRIDED, stride=2 + 33 * depth) if strided else {}
+                    tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth, **kw)
+                    tr.render(1)
+                    tr.render(spp - 1)
+                    img, rng, got = tr.readback(), tr.readback_rng(), tr.stats()
+            finally:
+                os.environ.pop("PT_LDS_TREE_OFF", None)
+            diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+            assert not diff.any(), f"{scene_name}, tree in {'global memory' if off else 'LDS'}: {int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+            assert got.rays == st.rays and (strided or np.array_equal(rng, ref_rng))
+    finally:
+        lib.pt_hip_set_bvh_threshold(pt.PT_BVH_DEFAULT_MIN_TRIANGLES)
