@@ -34,6 +34,18 @@ def pack(pt, V, T, M):
     return bytes(blob)
 
 
+def pack_with_bvh(pt, V, T, M):
+    """pt_hip_scene_pack_ex(.., with_bvh = 1): a BVH whatever the triangle count (the plugin's second form of a small scene)"""
+    lib = pt.load_library()
+    v, t, m = pt.make_scene(V, T, M)
+    n = lib.pt_hip_scene_blob_bytes_ex(len(T), len(M), 1)
+    blob = (C.c_uint8 * n)()
+    assert lib.pt_hip_scene_pack_ex(C.cast(v, C.c_void_p), len(V), C.cast(t, C.c_void_p), len(T), C.cast(m, C.c_void_p), len(M),
+                                    C.cast(blob, C.c_void_p), n, 1) == 0, lib.pt_hip_last_error()
+    assert lib.pt_hip_scene_has_bvh(C.cast(blob, C.c_void_p), n) == 1
+    return bytes(blob)
+
+
 def make_rays(n_rays, seed, camera, lo=(-1.0, -1.0, -0.5), hi=(1.0, 1.0, 1.5)):
     rng = np.random.default_rng(seed)
     lo, hi = np.array(lo), np.array(hi)
@@ -103,6 +115,25 @@ def test_bvh_walk_equals_brute_force_on_the_host(pt, tmp_path, name, n_rays, cam
     if name.startswith("heap-") and check == CHECK:
         # the heap of large triangles is there to fill the stack: with the library's own sizing the walk must have gone beyond the LDS levels
         assert int(fields[7]) > int(fields[9]), r.stdout
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 4, 5, 9, 17, 48])
+def test_trees_of_a_few_triangles(pt, tmp_path, n_tris):
+    """pt_hip_scene_pack_ex packs a BVH for ANY triangle count: a single leaf wrapped into a root, wide nodes with two or three
+    children and empty slots, the all-materials scene (48 triangles: what the plugin holds in both forms).  Walk == loop, on the host."""
+    if not os.path.exists(CHECK):
+        pytest.skip("tests/host/bvh_host_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    V, T, M = scenes.all_materials_scene() if n_tris == 48 else scenes.triangle_soup(n_tris, 40 + n_tris)
+    blob, rays = tmp_path / "scene.blob", tmp_path / "rays.f32"
+    blob.write_bytes(pack_with_bvh(pt, V, T, M))
+    make_rays(3000, 5, (0.0, 0.0, 0.0)).tofile(rays)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    for check in (CHECK, CHECK_SPILL):
+        r = subprocess.run([check, str(blob), str(rays), "0", "0", "0"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        fields = r.stdout.split()
+        assert int(fields[1]) == 3000 and int(fields[5]) == 0, r.stdout
 
 
 @pytest.mark.parametrize("name,n_rays,lanes,first", [("synthetic-1500", 1400, 64, 0), ("synthetic-10000", 700, 64, 0), ("mixed", 1500, 64, 0),
