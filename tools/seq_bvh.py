@@ -9,6 +9,6 @@ for n in (1000, 10000, 100000):
             with pt.PathTracer(w, h) as tr:
                 tr.set_scene(*sc)
                 tr.set_options(engine=engine)
-                for _ in range(5): tr.render(8)          # (PT_ENGINE_AUTO measures its candidates on the first renders of a sample count)
+                for _ in range(8): tr.render(8)          # (PT_ENGINE_AUTO measures its candidates on the first renders of a sample count: one unmeasured, two per candidate)
                 s0 = tr.stats(); tr.render(8); s1 = tr.stats()
                 print(f"{n} triangles {w}x{h} sequential {name:9s}: {(s1.rays - s0.rays) / (s1.total_render_ms - s0.total_render_ms) / 1e3:8.1f} Mrays/s  in use {s1.engine_in_use}", flush=True)
