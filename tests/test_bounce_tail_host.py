@@ -39,7 +39,7 @@ def run(pt, oracle, tmp_path, scene, n_rays, entry, depth, rng_mode=1, shading=0
 
 @needs_binary
 @pytest.mark.parametrize("name,n_rays,entry,depth,lanes", [("synthetic-1500", 1500, 2, 10, 64), ("mixed", 1300, 2, 16, 64), ("synthetic-700", 333, 1, 6, 37),
-                                                           ("soup-900", 1100, 3, 8, 64)])
+                                                           ("soup-300", 1100, 3, 8, 64)])
 def test_late_bounces_in_lanes_equal_the_staged_loop(pt, oracle, tmp_path, name, n_rays, entry, depth, lanes):
     """reference shading, strided streams (no stream words written): some paths reach a light, some bounce on"""
     lit, later = run(pt, oracle, tmp_path, scene_by_name(name), n_rays, entry, depth, lanes=lanes)

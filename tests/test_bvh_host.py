@@ -137,7 +137,7 @@ def test_trees_of_a_few_triangles(pt, tmp_path, n_tris):
 
 
 @pytest.mark.parametrize("name,n_rays,lanes,first", [("synthetic-1500", 1400, 64, 0), ("synthetic-10000", 700, 64, 0), ("mixed", 1500, 64, 0),
-                                                     ("synthetic-700", 333, 37, 0), ("synthetic-2500", 1200, 64, 1), ("soup-900", 1200, 64, 0)])
+                                                     ("synthetic-700", 333, 37, 0), ("synthetic-2500", 1200, 64, 1), ("soup-600", 600, 64, 0)])
 def test_extend_stage_as_a_wave_of_host_threads(pt, tmp_path, name, n_rays, lanes, first):
     """extend_bvh_block (what k_extend<false, true> runs) with diverging rays: every queue slot gets the brute-force hit.
     37 lanes: a partial wave, a ray count that is no multiple of it.  first = 1: the bounce-0 form, rays from the camera."""

@@ -74,7 +74,7 @@ def test_extended_shading_and_a_soup(pt, oracle, tmp_path):
     ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, shading=oracle.SHADING_EXTENDED), scene=oracle.make_scene(V, T, M))
     img, rng, rays = run(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth, shading=1)
     assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
-    V, T, M = scenes.triangle_soup(900, 31)
+    V, T, M = scenes.triangle_soup(300, 31)       # (300: every box overlaps most others, so each of the 256 lane threads walks most of the tree)
     ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp), scene=oracle.make_scene(V, T, M))
     img, rng, rays = run(pt, oracle, tmp_path, (V, T, M), w, h, spp, depth=depth)
     assert np.array_equal(bits(img), bits(ref)) and np.array_equal(rng, ref_rng) and rays == st.rays
