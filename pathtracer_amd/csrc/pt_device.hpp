@@ -537,8 +537,12 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	Vec3 dd{ fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x, fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y,
 	         fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z };
 	BvhRay r;
-	r.inv = Vec3{ bv.cell / dd.x, bv.cell / dd.y, bv.cell / dd.z };
-	float dlen = __builtin_sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
+	// v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE division and square root (11 and 15 instructions each, four and two of them
+	// per ray): nothing here reaches a hit's VALUE, only which boxes a walk enters, and every use carries a margin far above an ulp --
+	// a slab's two products use the SAME inv, so its error scales that axis' parameters by 1 +- 1.2e-7 against box_hit's relative
+	// hair of 1e-5; |d| enters S through factors of 1.05 and the interval's widening through 1.01
+	r.inv = Vec3{ bv.cell * __builtin_amdgcn_rcpf(dd.x), bv.cell * __builtin_amdgcn_rcpf(dd.y), bv.cell * __builtin_amdgcn_rcpf(dd.z) };
+	float dlen = __builtin_amdgcn_sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
 	// S for THIS ray (S >= |origin - v0| + 0.86 edge, pt_bvh.hpp): an accepted hit has computed t < best_t and its true plane point
 	// lies within delta of the triangle, every point of which is within an edge's length of v0 -- so |origin - v0| <= best_t |d| +
 	// edge + 2 delta (the error of t and the displacement, both bounded with the launch-wide S), and S <= best_t |d| + 2 edges +
@@ -564,7 +568,7 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 		// distance, not the room's size (what s_bound and the scene's longest edge say)
 		const float e_free = bv.free_bounds[0], r_free = bv.free_bounds[4];
 		const float ox = o.x - bv.free_bounds[1], oy = o.y - bv.free_bounds[2], oz = o.z - bv.free_bounds[3];
-		const float s_sphere = 1.0001f * (__builtin_sqrtf(ox * ox + oy * oy + oz * oz) + r_free + e_free) + 1e-6f;
+		const float s_sphere = 1.0001f * (__builtin_amdgcn_sqrtf(ox * ox + oy * oy + oz * oz) + r_free + e_free) + 1e-6f;
 		const float s_launch = fminf(bv.s_bound, s_sphere);                   // (NaN / inf from a degenerate triangle: fminf keeps s_bound)
 		const float dmax_free = bv.kappa_free * s_launch + bv.slack;
 		const float s_free = fminf(s_launch, 1.05f * (best_t * dlen + 2.0f * e_free) + 2.0f * dmax_free);
@@ -590,7 +594,7 @@ __device__ __forceinline__ BvhRay bvh_ray_setup(const BvhView& bv, Vec3 o, Vec3 
 	delta_t += extra_grow;
 	// the same bound holds for the hit distance (t = f * (e1 . q) carries the same 1 / det): |t_true - t| |d| <= delta_t,
 	// so the ray interval is widened to [-dt, best_t + dt] with it
-	r.dt = 1.01f * delta_t / dlen;
+	r.dt = 1.01f * delta_t * __builtin_amdgcn_rcpf(dlen);
 	// The origin in grid units.  Its own rounding (a subtraction, a product with the rounded 1/cell: under 4 ulp of a
 	// value that can reach 65535 + the camera's distance) and that of the slab's (q - o) go into the inflation, four
 	// times over: 1e-6 of the magnitudes involved -- hundredths of a cell, against boxes tens of cells wide.
@@ -670,6 +674,9 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 			if (leafy > 0 && (__popcll(walking) < kBvhQuorum || (PT_BVH_RATIO > 0 && __popcll(walking) * PT_BVH_RATIO < leafy * 4))) break;
 		}
 		PT_COUNT_WAVE((uint32_t)cur < (uint32_t)kBvhSwitch, 0, 1);
+		// (wide nodes: can every walking lane stack three more children in LDS?  a ballot here, where the whole wave is: the pushes
+		// themselves sit in the lanes' own branch)
+		const bool roomy = PT_BVH_WIDE && __ballot((uint32_t)cur < (uint32_t)kBvhSwitch && sp + 4 > bv.stack_depth) == 0ull;
 		if ((uint32_t)cur < (uint32_t)kBvhSwitch) {
 			PT_CHECK((uint32_t)cur < bv.n_nodes && sp >= 0 && sp <= bv.stack_total, { cur = kBvhDone; sp = 0; continue; });
 #if PT_BVH_WIDE
@@ -688,7 +695,17 @@ __device__ __forceinline__ void bvh_round(const BvhView& bv, BvhRay& r, Vec3 o, 
 			const uint32_t q0 = key32(h0, tn0, 0u), q1 = key32(h1, tn1, 1u), q2 = key32(h2, tn2, 2u), q3 = key32(h3, tn3, 3u);
 			const uint32_t qm = min(min(q0, q1), min(q2, q3));
 			if (qm == 0xFFFFFFFFu) cur = bvh_pop(bv, stack, sp);
-			else {
+			else if (roomy) {
+				// every walking lane of the wave has three free levels in the LDS part (the usual case by far): each child is stored
+				// at the running top unconditionally and the top moves on only if the child is deferred -- a store that does not count
+				// is overwritten by the next one or stays above the top -- no branch, no bounds check per push
+				uint32_t* top = stack.lds + sp * 256;
+				*top = w3.w; if (h3 && q3 != qm) { top += 256; sp++; }
+				*top = w2.w; if (h2 && q2 != qm) { top += 256; sp++; }
+				*top = w1.w; if (h1 && q1 != qm) { top += 256; sp++; }
+				*top = w0.w; if (h0 && q0 != qm) { top += 256; sp++; }
+				cur = (int32_t)(qm == q0 ? w0.w : qm == q1 ? w1.w : qm == q2 ? w2.w : w3.w);
+			} else {
 				if (h3 && q3 != qm) bvh_push(bv, stack, sp, w3.w);
 				if (h2 && q2 != qm) bvh_push(bv, stack, sp, w2.w);
 				if (h1 && q1 != qm) bvh_push(bv, stack, sp, w1.w);
