@@ -16,6 +16,7 @@ for wl in ${WORKLOADS:-default c5 c4_10k c4_100k}; do
     i=0
     for c in "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE"; do
       i=$((i+1))
+      rm -rf $OUT/pmc_${wl}_${eng}_p$i
       timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${wl}_${eng}_p$i -- python3 bench.py --bare --workload $wl --engine $eng --steps $STEPS --warmup $WARM --settle-seconds 0 > $OUT/pmc_${wl}_${eng}_p$i.log 2>&1 || echo "pass $wl $eng $i failed"
       echo "pass $wl $eng $i done"
     done

@@ -25,6 +25,7 @@ traces)
   export PT_BENCH_MARKER=1
   for wl in $WORKLOADS; do
     for eng in $ENGINES; do
+      rm -rf $OUT/kt_${wl}_${eng}          # (a directory left by an earlier run would be summarised together with this one)
       timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_${wl}_${eng} -- python3 bench.py --bare --workload $wl --engine $eng --steps 50 --warmup 2 > $OUT/kt_${wl}_${eng}.log 2>&1 || { echo "kernel trace $wl $eng failed"; tail -5 $OUT/kt_${wl}_${eng}.log; exit 1; }
       python3 tools/steady.py $OUT/kt_${wl}_${eng} $OUT/kt_${wl}_${eng}_steady.csv
       grep "^{" $OUT/kt_${wl}_${eng}.log > $OUT/kt_${wl}_${eng}_bench.json || true
