@@ -66,8 +66,10 @@ enum { PT_SHADING_REFERENCE = 0, PT_SHADING_EXTENDED = 1 };
  * process-wide threshold, so a blob packed under one threshold stays valid after pt_hip_set_bvh_threshold changes it. */
 #define PT_FRAME_SCENE_BVH 2u
 /* Scenes of MORE triangles than this are packed with a BVH unless pt_hip_set_bvh_threshold says otherwise.  Measured on
- * MI355X at 1080p (tools/bvh_crossover.py, profiles/r02_bvh_crossover.txt): the 48-triangle all-materials scene runs 1.5 .. 1.8x
- * faster looped over from LDS when samples are batched, at 108 triangles the BVH leads 1.4 .. 2.5x, at 192 2 .. 4x. */
+ * MI355X at 1080p (tools/bvh_crossover.py, profiles/r03_bvh_crossover.txt): at 108 triangles the BVH leads 1.9 .. 3x whatever the
+ * samples per call; the 48-triangle all-materials scene runs 1.17x faster looped over from LDS with 64 strided samples per call and
+ * 2.8x SLOWER at one sample per call -- so below this limit (down to PT_BVH_DUAL_MIN_TRIANGLES, pt_plugin.h) the plugin keeps a scene in
+ * both forms and measures. */
 #define PT_BVH_DEFAULT_MIN_TRIANGLES 96u
 /* PT_FRAME_OUT_OF_STEP (pt_hip_render_fused, scenes without a BVH): the 64 pixels of a wave take their samples out of step --
  * a lane whose path has ended starts its pixel's next sample while its neighbours still bounce -- instead of bounce by bounce
@@ -224,8 +226,8 @@ int pt_hip_generate(const pt_frame* frame, uint32_t frame_first, uint32_t n_samp
 /* a5+a6: TraverseScene + RayIntersectsTriangle (kernels.cu:57-69, Functions.cuh:56-89).
  * For every queued entry (counts[b] per block): closest accepted hit (t > EPSILON && t < best_t,
  * first index wins ties), written as hit[slot] = {t or unchanged best_t, triangle index or
- * 0xFFFFFFFF}.  Scenes of up to 512 triangles loop over all of them (from LDS) like the reference;
- * larger ones carry a BVH in their blob and are traversed with it -- a culling structure only,
+ * 0xFFFFFFFF}.  Blobs without a BVH (up to PT_BVH_DEFAULT_MIN_TRIANGLES triangles by default) are looped over (from LDS) like the reference;
+ * blobs that carry one (PT_FRAME_SCENE_BVH in the frame) are traversed with it -- a culling structure only,
  * the accepted hit is the brute-force one bit for bit (pathtracer_amd/csrc/pt_bvh.hpp). */
 int pt_hip_extend(const pt_frame* frame, uint32_t bounce, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                   pt_queue in, const uint32_t* counts, uint32_t capacity, void* hit, void* stream);
