@@ -107,6 +107,7 @@ class PathTracer final : public IPathTracer {
 	size_t _workspaceBytes = 0, _stackedBytes = 0;
 	uint32_t _nTris = 0, _nMats = 0;
 	bool _sceneHasBvh = false;          // recorded when the scene is packed (pt_hip_scene_has_bvh), passed with every frame
+	bool _statsUnfolded = false;        // fused renders have left counts in the partial sums since the last fold (_FoldStats)
 	bool _sceneDual = false;            // a small scene held in both forms: _dev.scene loops over all triangles, _dev.scene_walk carries a BVH (pt_plugin.h)
 	uint64_t _sceneHash = 0;            // FNV-1a of the packed blob: a state file is only resumed on the scene it was saved on
 	int _device = -1;                   // resolved HIP ordinal of this instance, bound by every method (DeviceScope)
@@ -468,6 +469,7 @@ public:
 		DeviceScope bind(_device);
 		if (_drawState == Drawing) FinalizeDrawing();
 		uint64_t words[PT_STATS_PUBLIC_WORDS];
+		if (int rc = _FoldStats()) return rc;
 		PT_TRY(pt_hip_memcpy_d2h(words, _dev.stats, sizeof(words), _stream));
 		std::memset(out, 0, sizeof(*out));
 		out->rays = words[0]; out->diffuse_bounces = words[1]; out->paths = words[2];
@@ -518,6 +520,7 @@ public:
 		hd.frame_number = _frameNumber; hd.local_shards = _localShards; hd.pitch = _pitch; hd.n_tris = _nTris; hd.n_mats = _nMats;
 		hd.scene_hash = _sceneHash; hd.options = _opt; hd.camera = _camera.Data();
 		hd.total_ms = _totalMs; hd.renders = _renders;
+		if (int rc = _FoldStats()) return rc;
 		PT_TRY(pt_hip_memcpy_d2h(hd.stats, _dev.stats, sizeof(hd.stats), _stream));
 		std::vector<uint32_t> rng(_pixelCount);
 		std::vector<float> mean((size_t)_pitch * _localShards * 4);
@@ -727,10 +730,19 @@ private:
 		pt_frame f = _Frame();
 		PT_TRY(pt_hip_rng_seed(&f, _dev.rng, _stream));
 		PT_TRY(pt_hip_memset(_dev.stats, 0, PT_STATS_WORDS * sizeof(uint64_t), _stream));
+		_statsUnfolded = false;
 		return PT_OK;
 	}
 
+	// The fused engine's kernels leave their ray counts in the statistics array's partial sums (PT_FRAME_DEFER_FOLD on every render);
+	// they are folded here, when somebody reads the counters, not by a launch of its own behind every render -- 4 us of the 61 us a
+	// one-sample call of the reference's scene takes, the regime an IPathTracer host runs in.
+	int _FoldStats() {
+		if (_statsUnfolded) { PT_TRY(pt_hip_fold_stats(_dev.stats, _stream)); _statsUnfolded = false; }
+		return PT_OK;
+	}
 	int _ReadRays(uint64_t* rays) {
+		if (int rc = _FoldStats()) return rc;
 		PT_TRY(pt_hip_memcpy_d2h(rays, _dev.stats, sizeof(uint64_t), _stream));
 		return PT_OK;
 	}
@@ -813,6 +825,7 @@ private:
 		}
 		_candInFlight = cand;
 		_imageCurrent = false;
+		if (engine == PT_ENGINE_FUSED) { f.flags |= PT_FRAME_DEFER_FOLD; _statsUnfolded = true; }      // folded when read: _FoldStats
 		// (inside the timed region: the device time the statistics report includes it -- except under a probe, where the one walk per
 		// pixel would be charged to whichever BVH candidate happens to run first)
 		const bool lists_now = walk && !_listsValid && (uint64_t)_frameNumber + samples >= kListsFromSample && !std::getenv("PT_PRIMARY_LISTS");
@@ -847,7 +860,7 @@ private:
 				PT_TRY(pt_hip_event_create(&_evFork));
 				for (uint32_t k = 0; k < kSideStreams; k++) { PT_TRY(pt_hip_stream_create(&_side[k])); PT_TRY(pt_hip_event_create(&_evJoin[k])); }
 			}
-			f.flags |= PT_FRAME_DEFER_FOLD;          // one fold, after the join: a fold zeroes partial sums another stream's kernel is adding to
+			// (PT_FRAME_DEFER_FOLD is set: a fold would zero partial sums another stream's kernel is adding to)
 			PT_TRY(pt_hip_event_record(_evFork, _stream));
 			for (uint32_t k = 0; k < kSideStreams; k++) PT_TRY(pt_hip_stream_wait_event(_side[k], _evFork));
 		}
@@ -869,7 +882,6 @@ private:
 				PT_TRY(pt_hip_event_record(_evJoin[k], _side[k]));
 				PT_TRY(pt_hip_stream_wait_event(_stream, _evJoin[k]));
 			}
-			PT_TRY(pt_hip_fold_stats(_dev.stats, _stream));
 		}
 		PT_TRY(pt_hip_event_record(_evStop, _stream));
 		_inFlightSamples = samples;
