@@ -998,8 +998,8 @@ __device__ __forceinline__ Vec3 primary_direction(const FrameDev& f, uint32_t px
 //     v < 0  <=>  B = D.q < 0,       u + v > 1  <=>  A + B - det > 0                    (det > 0 where they are reached)
 // so if ONE of them holds at all four corners -- by a margin of 1e-4 of the magnitudes involved, two orders above the
 // fp32 rounding of the traced ray's own arithmetic and of the corners' -- it holds for every ray of the pixel, the test
-// would reject, and the triangle need not be looked at.  A lane works this out once per pixel (per launch or pass), the
-// wave ORs its 64 pixels together (adjacent pixels: they see the same few triangles), and intersect_range_primary skips
+// would reject, and the triangle need not be looked at.  A wave works this out once for its 64 pixels (per launch or pass:
+// primary_need_mask below, the same argument on the rectangle the pixels fill), and intersect_range_primary skips
 // what no lane needs: on the reference's scene the camera sees one or two of the four triangles.  Culling only skips
 // tests that cannot succeed, so results do not change.  Scenes of more than 64 triangles: everything is "needed".
 __device__ __forceinline__ Vec3 screen_point(const FrameDev& f, float xs, float ys) {
@@ -1029,23 +1029,69 @@ __device__ __forceinline__ bool corners_can_hit(const Vec3* corner, float dmax, 
 	return !(det_neg || a_neg || b_neg || u_gt1 || uv_gt1);
 }
 
+// The wave's mask, the same word in every lane.  The 64 pixels of a wave are consecutive (lane order = pixel order, both engines),
+// so they fill a run of one row or a few whole rows: the tests run ONCE PER WAVE on that rectangle's four corners -- its patch is
+// the convex hull of its pixels' patches, (x + u) / width is monotonic in x, so what holds at the rectangle's corners holds for every
+// ray of every pixel in it -- with one TRIANGLE per lane: 64 triangles cost what one used to, where a lane per pixel spent the four
+// corners of every triangle on its own pixel and the wave then ORed 64 nearly equal answers (one sample per call of the reference's
+// scene: more instructions than the sample itself; 48 triangles: fifteen times the sample).  A rectangle can fail to exclude a
+// triangle that each of its pixels excludes by a different test; that costs a test that fails, never a result.
+#ifdef PT_SHIM_WAVE                      // tests/host/hip_shim: a wave of 1..64 host threads
+__device__ __forceinline__ uint32_t wave_lane() { return shim_wave_lane(); }
+#else
+__device__ __forceinline__ uint32_t wave_lane() { return threadIdx.x & 63u; }
+#endif
+// the rectangle of pixels (fx, fy) .. (lx, ly) in reading order: its four corner directions and the margin's scale
+struct NeedRect { Vec3 corner[4]; float dmax; };
+__device__ __forceinline__ NeedRect need_rect(const FrameDev& f, uint32_t fx, uint32_t fy, uint32_t lx, uint32_t ly) {
+	const bool one_row = fy == ly;
+	// the patch: (x + u) / width with u in (0, 1], rounded; IEEE division is monotonic, the fast form returns the same bits
+	float x0 = one_row ? (float)fx / (float)f.width : 0.0f, x1 = one_row ? ((float)lx + 1.0f) / (float)f.width : 1.0f;
+	float y0 = (float)fy / (float)f.height, y1 = ((float)ly + 1.0f) / (float)f.height;
+	NeedRect r;
+	r.corner[0] = screen_point(f, x0, y0); r.corner[1] = screen_point(f, x1, y0); r.corner[2] = screen_point(f, x0, y1); r.corner[3] = screen_point(f, x1, y1);
+	r.dmax = 1e-4f * fmaxf(fmaxf(l1norm(r.corner[0]), l1norm(r.corner[1])), fmaxf(l1norm(r.corner[2]), l1norm(r.corner[3])));
+	return r;
+}
+__device__ __forceinline__ bool rect_can_hit(const NeedRect& r, const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t k) {
+	float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
+	float4 pa = prim[2 * k + 0], pb = prim[2 * k + 1];
+	Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x }, s{ pa.x, pa.y, pa.z }, q{ pb.x, pb.y, pb.z };
+	return corners_can_hit(r.corner, r.dmax, e0, e1, s, q);
+}
+
 __device__ __forceinline__ unsigned long long primary_need_mask(const FrameDev& f, uint32_t px, uint32_t py, bool active,
                                                                 const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t n_tris) {
 	if (n_tris > 64u) return ~0ull;
-	// the patch: (x + u) / width with u in (0, 1], rounded; IEEE division is monotonic, the fast form returns the same bits
-	float x0 = (float)px / (float)f.width, x1 = ((float)px + 1.0f) / (float)f.width;
-	float y0 = (float)py / (float)f.height, y1 = ((float)py + 1.0f) / (float)f.height;
-	Vec3 c0 = screen_point(f, x0, y0), c1 = screen_point(f, x1, y0), c2 = screen_point(f, x0, y1), c3 = screen_point(f, x1, y1);
-	float dmax = 1e-4f * fmaxf(fmaxf(l1norm(c0), l1norm(c1)), fmaxf(l1norm(c2), l1norm(c3)));
+	const unsigned long long act = __ballot(active);
+	if (act == 0ull) return 0ull;
+	const int first = __builtin_ctzll(act), last = 63 - __builtin_clzll(act);
+	const NeedRect rect = need_rect(f, __shfl(px, first, 64), __shfl(py, first, 64), __shfl(px, last, 64), __shfl(py, last, 64));
+	// the lanes that are HERE share the triangles (a launch's last wave holds fewer than 64: k_fused's pixel loop leaves the rest
+	// outside); they are a run of consecutive lanes, or this does not cull
+	const unsigned long long here = __ballot(true);
+	const uint32_t h_first = (uint32_t)__builtin_ctzll(here), h_count = (uint32_t)__popcll(here);
+	if (here != ((h_count >= 64u ? 0ull : (1ull << h_count)) - 1ull) << h_first) return ~0ull;
 	unsigned long long need = 0ull;
-	for (uint32_t k = 0; k < n_tris; k++) {
-		float4 r0 = tris[4 * k + 0], r1 = tris[4 * k + 1], r2 = tris[4 * k + 2];
-		float4 pa = prim[2 * k + 0], pb = prim[2 * k + 1];
-		Vec3 e0{ r0.w, r1.x, r1.y }, e1{ r1.z, r1.w, r2.x }, s{ pa.x, pa.y, pa.z }, q{ pb.x, pb.y, pb.z };
-		const Vec3 corner[4] = { c0, c1, c2, c3 };
-		bool can_hit = active && corners_can_hit(corner, dmax, e0, e1, s, q);
-		if (__ballot(can_hit) != 0ull) need |= 1ull << k;
+	for (uint32_t base = 0; base < n_tris; base += h_count) {
+		const uint32_t k = base + (wave_lane() - h_first);
+		const bool can_hit = k < n_tris && rect_can_hit(rect, tris, prim, k);
+		need |= (__ballot(can_hit) >> h_first) << base;
 	}
+	return need;
+}
+
+// The same word for the 64 pixels that start at local pixel 64 * word, worked out by ONE lane (k_need_masks: a lane per word, a
+// loop over the triangles -- 500 waves for a 1080p frame instead of 32 400).  0 for words past the image.
+__device__ __forceinline__ unsigned long long need_mask_of_word(const FrameDev& f, uint32_t word, const float4* __restrict__ tris, const float4* __restrict__ prim, uint32_t n_tris) {
+	if (n_tris > 64u) return ~0ull;
+	const uint64_t li0 = (uint64_t)word * 64u;
+	if (li0 >= f.pixel_count) return 0ull;
+	const uint32_t i0 = f.pixel_first + (uint32_t)li0, i1 = f.pixel_first + (li0 + 63u < f.pixel_count ? (uint32_t)li0 + 63u : f.pixel_count - 1u);
+	const NeedRect rect = need_rect(f, i0 % (uint32_t)f.width, i0 / (uint32_t)f.width, i1 % (uint32_t)f.width, i1 / (uint32_t)f.width);
+	unsigned long long need = 0ull;
+	for (uint32_t k = 0; k < n_tris; k++)
+		if (rect_can_hit(rect, tris, prim, k)) need |= 1ull << k;
 	return need;
 }
 

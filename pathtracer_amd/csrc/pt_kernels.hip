@@ -543,6 +543,17 @@ __global__ __launch_bounds__(kBlock, PT_TAIL_WAVES) void k_bounce_tail(FrameDev 
 	if (threadIdx.x > entry_bounce && threadIdx.x <= f.depth) counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_count[threadIdx.x];
 }
 
+// Ahead of a call's first pass: the culling masks of its camera rays (pt_wavefront.hpp, need_masks_block), and the per-block ray
+// counters the passes add to start at zero (n_counts words; 0: nobody reads them).
+__global__ __launch_bounds__(kBlock) void k_need_masks(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris,
+                                                       unsigned long long* __restrict__ need_masks, uint32_t n_words,
+                                                       uint32_t* __restrict__ ray_counts, uint32_t n_counts) {
+	__shared__ float4 s_prim[128];
+	if (!scene_guard(scene, n_tris, false)) return;
+	for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_counts; k += gridDim.x * kBlock) ray_counts[k] = 0u;
+	need_masks_block(f, reinterpret_cast<const float4*>(scene + sizeof(SceneHeader)), n_tris, s_prim, need_masks, n_words);
+}
+
 // One pass of an LDS-resident scene in ONE launch: stages the block's LDS, then bounces_block (pt_wavefront.hpp).
 template <bool SEQ>
 __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigned char* __restrict__ scene, uint32_t n_tris, uint32_t n_mats,
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
                                                        float4* __restrict__ radiance, unsigned char* __restrict__ lit, uint32_t* __restrict__ rng_out,
                                                        JumpMat pass_first, JumpMat per_sample, const uint32_t* __restrict__ rng_in,
                                                        uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending,
-                                                       unsigned long long* __restrict__ need_masks, uint32_t need_masks_valid) {
+                                                       const unsigned long long* __restrict__ need_masks) {
 	extern __shared__ float4 s_scene[];
 	__shared__ uint32_t s_jump[1024];
 	__shared__ uint32_t s_stride[1024];       // STRIDED: byte tables of step^stride
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_bounces(FrameDev f, const unsigne
 	if (threadIdx.x == 0) { s_out = 0; s_traced = 0; s_round[0] = 0; s_round[1] = 0; }
 	__syncthreads();
 	ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, capacity, radiance, lit, rng_out, &s_out, &s_traced };
-	bounces_block<SEQ>(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending, need_masks, need_masks_valid != 0u, s_round);
+	bounces_block<SEQ>(c, s_prim, s_stride, a0, b0, c0, pid0, hit0, a1, b1, c1, pid1, hit1, ray_counts, pass_mat, rng_in, n_samples, mean_first, mean, first_pending, need_masks, s_round);
 }
 
 // a10. One thread per pixel, the pass's samples folded in order.
@@ -600,19 +611,20 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(uint32_t pixel_count, uin
 	}
 }
 
-// per-pass, per-block counters -> 64-bit totals; block x sums bounce x over the G queue blocks
+// per-pass, per-block counters -> 64-bit totals; block (part, bounce) sums kBlock of bounce's G counters -- one load per thread (a
+// block per bounce that looped over all G took 9.3 us of a one-sample call's 70: eight dependent trips to memory)
 __global__ __launch_bounds__(kBlock) void k_fold_counts(const uint32_t* __restrict__ counts, uint32_t G, uint32_t depth,
                                                         unsigned long long* __restrict__ stats) {
 	__shared__ unsigned long long s_sum[kBlock / 64];
-	uint32_t bounce = blockIdx.x;
-	unsigned long long v = 0;
-	for (uint32_t b = threadIdx.x; b < G; b += kBlock) v += counts[(size_t)bounce * G + b];
+	const uint32_t bounce = blockIdx.y, b = blockIdx.x * kBlock + threadIdx.x;
+	unsigned long long v = b < G ? counts[(size_t)bounce * G + b] : 0u;
 	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
 	if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		unsigned long long total = 0;
 		for (int k = 0; k < kBlock / 64; k++) total += s_sum[k];
+		if (total == 0ull) return;
 		if (bounce < depth) { atomicAdd(&stats[0], total); atomicAdd(&stats[4 + bounce], total); }
 		if (bounce >= 1) atomicAdd(&stats[1], total);
 		if (bounce == 0) atomicAdd(&stats[2], total);
@@ -922,7 +934,7 @@ struct Workspace {
 	uint32_t* ray_counts; // same shape: rays traced per bounce, where terminal hits never enter the queue (k_shade RESOLVE)
 	uint32_t* smat;      // max(samples_per_pass, 2) x 32 words (STRIDED)
 	uint32_t* first_pending;   // per pixel: the first sample of the pass whose frame the one-launch pass did not fold from registers
-	unsigned long long* need_masks;   // per 64 pixels: the triangles their camera rays can reach (primary_need_mask), kept across the passes of a call
+	unsigned long long* need_masks;   // per 64 pixels: the triangles their camera rays can reach (k_need_masks), for the passes of a call
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Queue capacity of a pass.  The one-launch pass (k_bounces) gives block b the pixel chunks {k : k % G == b} with all
@@ -1435,17 +1447,21 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 				host_jump_matrix((uint64_t)(frame_first + done) * frame->stride, first.cols);
 				host_jump_matrix(frame->stride, per.cols);
 			}
-			if (done == 0 && stats) HIP_TRY(hipMemsetAsync(w.ray_counts, 0, (size_t)(frame->depth + 1) * G * sizeof(uint32_t), s));
+			if (done == 0) {
+				const uint32_t n_words = (uint32_t)((((size_t)frame->pixel_count + kBlock - 1) / kBlock) * (kBlock / 64));      // as carve() sizes them
+				hipLaunchKernelGGL(k_need_masks, dim3((n_words + kBlock - 1) / kBlock), dim3(kBlock), 0, s, f, (const unsigned char*)scene_blob, si.n_tris, w.need_masks, n_words,
+				                   w.ray_counts, stats ? (frame->depth + 1) * G : 0u);
+			}
 			size_t lds_bytes = bounces_lds_bytes(si);
 #define PT_BOUNCES(SEQ) hipLaunchKernelGGL(k_bounces<SEQ>, dim3(G), dim3(kBlock), lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, \
 			                   w.a[0], w.b[0], w.c[0], w.pid[0], w.hit[0], w.a[1], w.b[1], w.c[1], w.pid[1], w.hit[1], \
 			                   w.ray_counts, slots, w.radiance, w.lit, SEQ ? rng : nullptr, \
-			                   first, per, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending, w.need_masks, done != 0u ? 1u : 0u)
+			                   first, per, (const uint32_t*)rng, ns, mean_first + done, (float4*)mean, w.first_pending, w.need_masks)
 			if (sequential) PT_BOUNCES(true); else PT_BOUNCES(false);
 #undef PT_BOUNCES
 			// uint32 counters: fold before a block's share of a bounce can pass 2^32 rays (it owns at most `slots / G / ns` pixels)
 			bool last_pass = done + per_launch >= n_samples;
-			if (stats && last_pass) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.ray_counts, G, frame->depth, (unsigned long long*)stats);
+			if (stats && last_pass) hipLaunchKernelGGL(k_fold_counts, dim3((G + kBlock - 1) / kBlock, frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.ray_counts, G, frame->depth, (unsigned long long*)stats);
 		} else {
 			// camera rays through their pixels' leaf lists: made, intersected, shaded and queued in one launch (k_camera_lists)
 			if (!camera_fused) {
@@ -1499,7 +1515,7 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 			hipLaunchKernelGGL(k_accumulate, dim3(grid_for(frame->pixel_count)), dim3(kBlock), 0, s,
 			                   frame->pixel_count, mean_first + done, ns, (const float4*)w.radiance, (const unsigned char*)w.lit, (float4*)mean);
 		}
-		if (stats && !fuse) hipLaunchKernelGGL(k_fold_counts, dim3(frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.counts, G, frame->depth, (unsigned long long*)stats);
+		if (stats && !fuse) hipLaunchKernelGGL(k_fold_counts, dim3((G + kBlock - 1) / kBlock, frame->depth + 1), dim3(kBlock), 0, s, (const uint32_t*)w.counts, G, frame->depth, (unsigned long long*)stats);
 		HIP_TRY(hipGetLastError());
 	}
 	return PT_OK;

@@ -214,6 +214,17 @@ constexpr uint32_t kSeqQueued = 0x80000000u;
 #define PT_SEQ_QUORUM_NUM 1u
 #define PT_SEQ_QUORUM_DEN 2u
 #endif
+// The camera-ray culling masks of a call, one word per 64 pixels, for bounces_block: a launch of its own ahead of the first pass
+// (k_need_masks), a LANE per word (need_mask_of_word).  s_prim: 2 x n_tris float4 of the block's LDS (n_tris <= 64; more triangles:
+// every word is ~0 and s_prim is not touched).
+__device__ __forceinline__ void need_masks_block(const FrameDev& f, const float4* __restrict__ tris, uint32_t n_tris, float4* __restrict__ s_prim,
+                                                 unsigned long long* __restrict__ need_masks, uint32_t n_words) {
+	if (n_tris <= 64u) stage_primary_records(tris, n_tris, Vec3{ f.origin.x, f.origin.y, f.origin.z }, s_prim);
+	__syncthreads();
+	for (uint32_t word = blockIdx.x * blockDim.x + threadIdx.x; word < n_words; word += gridDim.x * blockDim.x)
+		need_masks[word] = need_mask_of_word(f, word, tris, s_prim, n_tris);
+}
+
 template <bool SEQ>
 __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* __restrict__ s_prim, const uint32_t* __restrict__ s_stride,
                                               float4* __restrict__ a0, float4* __restrict__ b0, float4* __restrict__ c0, uint32_t* __restrict__ pid0, uint2* __restrict__ hit0,
@@ -221,7 +232,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
                                               uint32_t* __restrict__ ray_counts,
                                               const uint32_t* __restrict__ pass_mat, const uint32_t* __restrict__ rng_in,
                                               uint32_t n_samples, uint32_t mean_first, float4* __restrict__ mean, uint32_t* __restrict__ first_pending,
-                                              unsigned long long* __restrict__ need_masks, bool need_masks_valid, uint32_t* s_round) {
+                                              const unsigned long long* __restrict__ need_masks, uint32_t* s_round) {
 	const FrameDev& f = c.f;
 	const uint32_t n_tris = c.n_tris;
 	const bool det_bounded = c.det_bounded;
@@ -244,15 +255,9 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 				uint32_t i = f.pixel_first + (active ? li : 0u);
 				uint32_t px = i % (uint32_t)f.width, py = i / (uint32_t)f.width;
 				uint32_t traced_acc = 0;                            // wave-uniform: rays this wave traced for bounce 1 in this chunk
-				// which triangles this wave's 64 pixels can see: worked out in the first pass of a render call, kept per wave
-				// (one word per 64 pixels) for the passes that follow -- it depends on the pixels and the camera only
-				unsigned long long need;
-				const uint32_t wave_slot = li0 / 64u + (threadIdx.x >> 6);
-				if (need_masks_valid || !first_round) need = need_masks[wave_slot];
-				else {
-					need = primary_need_mask(f, px, py, active, c.tris, s_prim, n_tris);                       // every lane of the block is here
-					if ((threadIdx.x & 63u) == 0u) need_masks[wave_slot] = need;
-				}
+				// which triangles this wave's 64 pixels can see: one word per 64 pixels, worked out before the call's first pass
+				// (need_masks_block) -- it depends on the pixels and the camera only
+				const unsigned long long need = need_masks[li0 / 64u + (threadIdx.x >> 6)];
 				if (SEQ) {
 					// SEQUENTIAL streams: sample s+1 of a pixel starts where sample s stopped, so a lane makes its pixel's samples
 					// one after the other for as long as each ends right here (its frame goes into the mean from registers, its

@@ -86,6 +86,23 @@ int main(int argc, char** argv) {
 	const float4* g_mats = g_tris + (size_t)n_tris * 4;
 	const bool det_bounded = (hdr->flags & kSceneDetBounded) != 0;
 
+	{   // k_need_masks, ahead of the first pass: one block here
+		float4* s_prim = exact<float4>(128);
+		gridDim.x = 1;
+		blockIdx.x = 0;
+		WaveShim block, waves[4];
+		block.lanes = 256;
+		for (auto& w : waves) w.lanes = 64;
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < 256; t++)
+			th.emplace_back([&, t] {
+				threadIdx.x = t;
+				t_wave = &waves[t / 64];
+				t_block = &block;
+				need_masks_block(f, g_tris, n_tris, s_prim, need_masks, chunks * 4);
+			});
+		for (auto& t : th) t.join();
+	}
 	unsigned long long rays = 0;
 	gridDim.x = G;
 	for (uint32_t done = 0; done < n_samples; done += per_launch) {
@@ -117,10 +134,10 @@ int main(int argc, char** argv) {
 					ShadeCtx c{ f, s_scene, s_scene + nt4, s_jump, n_tris, det_bounded, (uint32_t)slots, radiance, lit, sequential ? rng : nullptr, &s_out, &s_traced };
 					if (sequential)
 						bounces_block<true>(c, s_scene + nt4 + nm2, s_stride, qa[0], qb[0], qc[0], qpid[0], qhit[0], qa[1], qb[1], qc[1], qpid[1], qhit[1],
-						                    ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0, s_round);
+						                    ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, s_round);
 					else
 						bounces_block<false>(c, s_scene + nt4 + nm2, s_stride, qa[0], qb[0], qc[0], qpid[0], qhit[0], qa[1], qb[1], qc[1], qpid[1], qhit[1],
-						                     ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, done != 0, s_round);
+						                     ray_counts, pass_mat, rng, ns, frame_first + done, mean, first_pending, need_masks, s_round);
 				});
 			for (auto& t : th) t.join();
 		}

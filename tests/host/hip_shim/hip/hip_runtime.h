@@ -76,6 +76,8 @@ template <typename T> static inline T __shfl(T v, int src, int = 64) {
 	std::memcpy(&r, &all[src], sizeof(T));
 	return r;
 }
+#define PT_SHIM_WAVE 1
+static inline uint32_t shim_wave_lane() { return t_wave ? (threadIdx.x & 63u) : 0u; }
 static inline void __syncthreads() { if (t_block) t_block->barrier(); else if (t_wave) t_wave->barrier(); }
 static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 static inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
