@@ -102,6 +102,7 @@ typedef struct {
     uint32_t  shading;                   /* PT_SHADING_REFERENCE (default) or PT_SHADING_EXTENDED */
     uint32_t  flags;                     /* PT_FRAME_* */
     uint64_t  primary_lists;             /* 0, or the device address of this pixel range's camera-ray leaf lists (pt_hip_build_primary_lists) */
+    uint64_t  need_masks;                /* 0, or the device address of this pixel range's camera-ray culling masks (pt_hip_build_need_masks) */
     pt_float4 origin, top_left, bottom_left, bottom_right;  /* Camera.h:49-77 */
 } pt_frame;
 
@@ -186,6 +187,16 @@ int pt_hip_verify_fast_div(uint32_t denominator, int* ok, void* stream);
 size_t pt_hip_primary_lists_bytes(uint32_t pixel_count);
 int pt_hip_build_primary_lists(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                                void* lists, void* stream);
+
+/* ---- camera rays of scenes WITHOUT a BVH (same place in the reference; no counterpart there either).  The fused engine skips, per
+ * 64 consecutive pixels, the triangles no camera ray of theirs can be accepted by (scenes of up to 64 triangles; the argument:
+ * pt_device.hpp, primary_need_mask).  A launch works the masks out itself, once per wave -- or reads them from pt_frame.need_masks,
+ * built once per (scene blob, camera, image size, pixel range) by this call: at one sample per call, the reference's frame loop, the
+ * masks are a fifth of a render of its scene.  Same results either way.  `masks`: pt_hip_need_masks_bytes(pixel_count) bytes of
+ * device memory, one 64-bit word per 64 pixels of the range.  PT_FRAME_SCENE_BVH frames have no use for them (PT_ERR_INVALID). ---- */
+size_t pt_hip_need_masks_bytes(uint32_t pixel_count);
+int pt_hip_build_need_masks(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
+                            void* masks, void* stream);
 
 /* ---- a1: InitializeRng (kernels.cu:25-30) + RngInit (Functions.cuh:31-38).
  * rng[k] = step^((pixel_first+k)/32)(seed + pixel_first + k), by O(log) GF(2) jump-ahead

@@ -74,7 +74,7 @@ class CameraData(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixel_first", C.c_uint32), ("pixel_count", C.c_uint32),
                 ("depth", C.c_uint32), ("seed", C.c_uint32), ("rng_mode", C.c_uint32), ("stride", C.c_uint32),
-                ("shading", C.c_uint32), ("flags", C.c_uint32), ("primary_lists", C.c_uint64),
+                ("shading", C.c_uint32), ("flags", C.c_uint32), ("primary_lists", C.c_uint64), ("need_masks", C.c_uint64),
                 ("origin", Float4), ("top_left", Float4), ("bottom_left", Float4), ("bottom_right", Float4)]
 
 
@@ -170,6 +170,8 @@ SYMBOLS = {
     "pt_hip_scene_pack": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ]),
     "pt_hip_scene_pack_ex": (C.c_int, [_VP, _U32, _VP, _U32, _VP, _U32, _VP, _SZ, C.c_int]),
     "pt_hip_verify_fast_div": (C.c_int, [_U32, C.POINTER(C.c_int), _VP]),
+    "pt_hip_need_masks_bytes": (_SZ, [_U32]),
+    "pt_hip_build_need_masks": (C.c_int, [C.POINTER(Frame), _VP, _U32, _U32, _VP, _VP]),
     "pt_hip_primary_lists_bytes": (_SZ, [_U32]),
     "pt_hip_build_primary_lists": (C.c_int, [C.POINTER(Frame), _VP, _U32, _U32, _VP, _VP]),
     "pt_hip_rng_seed": (C.c_int, [_FRAMEP, _VP, _VP]),

@@ -946,6 +946,7 @@ struct FrameDev {
 	uint32_t fast_div;             // PT_FRAME_FAST_DIV: rcp_width / rcp_height may be used (verified per size)
 	float    rcp_width, rcp_height; // correctly rounded 1 / width, 1 / height
 	const uint32_t* primary_lists; // pt_frame::primary_lists (BVH scenes: per pixel of the range, the leaves its camera rays can reach) or null
+	const unsigned long long* need_masks; // pt_frame::need_masks (scenes without a BVH: per 64 pixels of the range, the triangles their camera rays can reach) or null
 	float4   origin, top_left, bottom_left, bottom_right;
 };
 
@@ -958,6 +959,7 @@ inline FrameDev to_dev(const pt_frame& f) {
 	d.fast_div = (f.flags & PT_FRAME_FAST_DIV) ? 1u : 0u;
 	d.rcp_width = 1.0f / (float)f.width; d.rcp_height = 1.0f / (float)f.height;      // host IEEE division: correctly rounded
 	d.primary_lists = reinterpret_cast<const uint32_t*>((uintptr_t)f.primary_lists);
+	d.need_masks = reinterpret_cast<const unsigned long long*>((uintptr_t)f.need_masks);
 	d.origin = float4{ f.origin.x, f.origin.y, f.origin.z, f.origin.w };
 	d.top_left = float4{ f.top_left.x, f.top_left.y, f.top_left.z, f.top_left.w };
 	d.bottom_left = float4{ f.bottom_left.x, f.bottom_left.y, f.bottom_left.z, f.bottom_left.w };
@@ -1041,6 +1043,13 @@ __device__ __forceinline__ uint32_t wave_lane() { return shim_wave_lane(); }
 #else
 __device__ __forceinline__ uint32_t wave_lane() { return threadIdx.x & 63u; }
 #endif
+// a word every lane of the wave holds the same value of, as the scalar the compiler cannot see it is (loaded per lane from a per-wave
+// address): loops over its bits then run on the scalar unit
+__device__ __forceinline__ unsigned long long wave_uniform(unsigned long long v) {
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+
 // the rectangle of pixels (fx, fy) .. (lx, ly) in reading order: its four corner directions and the margin's scale
 struct NeedRect { Vec3 corner[4]; float dmax; };
 __device__ __forceinline__ NeedRect need_rect(const FrameDev& f, uint32_t fx, uint32_t fy, uint32_t lx, uint32_t ly) {

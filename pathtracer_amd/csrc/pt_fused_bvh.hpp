@@ -240,7 +240,9 @@ __device__ __forceinline__ void fused_samples_out_of_step(const FusedLdsCtx& c, 
                                                           uint32_t& rng, float4& m, uint32_t& n_rays, uint32_t& n_diffuse) {
 	const FrameDev& f = c.f;
 	const bool extended = f.shading == PT_SHADING_EXTENDED;
-	const unsigned long long need = c.prim ? primary_need_mask(f, px, py, in_range, c.tris, c.prim, c.n_tris) : ~0ull;
+	// (a word of pt_frame::need_masks per 64 local pixels: the wave's lanes all read the same one; lane 0 is in range whenever any lane is)
+	const unsigned long long need = !c.prim ? ~0ull : f.need_masks ? wave_uniform(f.need_masks[in_range ? (py * (uint32_t)f.width + px - f.pixel_first) >> 6 : 0u])
+	                                                                           : primary_need_mask(f, px, py, in_range, c.tris, c.prim, c.n_tris);
 	uint32_t s = in_range ? 0u : c.n_samples;
 	bool has_ray = false;                // a bounce ray waits to be intersected
 	uint32_t b = 0, draws = 0;

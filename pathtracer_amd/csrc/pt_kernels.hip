@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kBlock, SCENE == 2 ? 5 : OUT_OF_STEP ? PT_FUSED_OOS
 		}
 		// the triangles this wave's pixels can see at all (none of the lanes here is out of range: the loop bound holds for li)
 		unsigned long long need = ~0ull;
-		if (use_prim) need = primary_need_mask(f, px, py, true, tris, s_prim, n_tris);
+		if (use_prim) need = f.need_masks ? wave_uniform(f.need_masks[li >> 6]) : primary_need_mask(f, px, py, true, tris, s_prim, n_tris);
 		for (uint32_t shard = 0; shard < ns; shard++) {
 		if (MAXS > 1 && shard != 0u) {
 			start = mat_apply_lds(s_first + 32u * shard, word);
@@ -1240,6 +1240,23 @@ int pt_hip_scene_pack_ex(const pt_vertex* vertices, uint32_t n_vertices,
 		r[2] = r[3] = 0.0f;
 		r[4] = materials[k].color.x; r[5] = materials[k].color.y; r[6] = materials[k].color.z; r[7] = materials[k].color.w;
 	}
+	return PT_OK;
+}
+
+size_t pt_hip_need_masks_bytes(uint32_t pixel_count) { return (((size_t)pixel_count + kBlock - 1) / kBlock) * (kBlock / 64) * sizeof(unsigned long long); }
+
+int pt_hip_build_need_masks(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials, void* masks, void* stream) {
+	if (int rc = check_frame(frame)) return rc;
+	if (!scene_blob || !masks) return fail(PT_ERR_INVALID, "build_need_masks: null pointer");
+	if (frame->flags & PT_FRAME_SCENE_BVH) return fail(PT_ERR_INVALID, "build_need_masks: BVH scenes cull their camera rays with per-pixel lists (pt_hip_build_primary_lists)");
+	if (frame->pixel_count == 0) return PT_OK;
+	SceneInfo si = scene_info(frame, n_triangles, n_materials);
+	FrameDev f = to_dev(*frame);
+	guard_ready();
+	const uint32_t n_words = (uint32_t)(pt_hip_need_masks_bytes(frame->pixel_count) / sizeof(unsigned long long));
+	hipLaunchKernelGGL(k_need_masks, dim3((n_words + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, f, (const unsigned char*)scene_blob, si.n_tris,
+	                   (unsigned long long*)masks, n_words, (uint32_t*)nullptr, 0u);
+	HIP_TRY(hipGetLastError());
 	return PT_OK;
 }
 

@@ -98,11 +98,13 @@ class PathTracer final : public IPathTracer {
 		void* image = nullptr;          // SAMPLE split: the combined image, _pitch float4
 		void* stacked = nullptr;        // SAMPLE split: shard-major staging of a combine (V x slice, or V x pitch on a gather root)
 		void* lists = nullptr;          // BVH scenes: per pixel, the leaves its camera rays can reach (pt_hip_build_primary_lists)
+		void* masks = nullptr;          // scenes of up to 64 triangles without a BVH, fused engine: per 64 pixels, the triangles their camera rays can reach (pt_hip_build_need_masks)
 	} _dev;
 	// The lists hold for one (scene, camera, size, pixel range): every restart of the accumulation drops them, and they are
 	// built again once the accumulation is worth it -- a build costs about two samples' worth of camera rays, so a host that
 	// moves its camera every frame never pays for one (kListsFromSample).  PT_PRIMARY_LISTS=off in the environment: never.
 	bool _listsValid = false;
+	bool _masksValid = false;
 	static constexpr uint32_t kListsFromSample = 3;
 	size_t _workspaceBytes = 0, _stackedBytes = 0;
 	uint32_t _nTris = 0, _nMats = 0;
@@ -235,7 +237,7 @@ public:
 		if (_stream) pt_hip_stream_synchronize(_stream);
 		if (_comm) pt_hip_comm_destroy(_comm);
 		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.scene); pt_hip_free(_dev.scene_walk);
-		pt_hip_free(_dev.stats); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked); pt_hip_free(_dev.lists);
+		pt_hip_free(_dev.stats); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked); pt_hip_free(_dev.lists); pt_hip_free(_dev.masks);
 		pt_hip_event_destroy(_evStart); pt_hip_event_destroy(_evStop);
 		for (uint32_t k = 0; k < kSideStreams; k++) {
 			if (_side[k]) { pt_hip_stream_synchronize(_side[k]); pt_hip_stream_destroy(_side[k]); }
@@ -700,9 +702,9 @@ private:
 		_ranks = l.ranks; _pixelFirst = l.pixel_first; _pixelCount = l.pixel_count;
 		_vShards = l.v_shards; _localShards = l.local_shards; _slice = l.slice; _pitch = l.pitch;
 		_imageCurrent = false;
-		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked); pt_hip_free(_dev.lists);
-		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _dev.image = nullptr; _dev.stacked = nullptr; _dev.lists = nullptr;
-		_listsValid = false;
+		pt_hip_free(_dev.rng); pt_hip_free(_dev.mean); pt_hip_free(_dev.workspace); pt_hip_free(_dev.image); pt_hip_free(_dev.stacked); pt_hip_free(_dev.lists); pt_hip_free(_dev.masks);
+		_dev.rng = nullptr; _dev.mean = nullptr; _dev.workspace = nullptr; _dev.image = nullptr; _dev.stacked = nullptr; _dev.lists = nullptr; _dev.masks = nullptr;
+		_listsValid = false; _masksValid = false;
 		_workspaceBytes = 0; _stackedBytes = 0;
 		// the short division of the ray set-up is used only for sizes it is verified for (exhaustively, on the device)
 		int okW = 0, okH = 0;
@@ -723,7 +725,7 @@ private:
 	// PathTracer.cu:235-244
 	int _InitializeRendering() {
 		_shouldRestartRendering = false;
-		_listsValid = false;                         // the camera, the scene or the pixel range may have changed
+		_listsValid = false; _masksValid = false;    // the camera, the scene or the pixel range may have changed
 		_frameNumber = 0;
 		_totalMs = 0.0; _renders = 0;
 		_imageCurrent = false;
@@ -836,9 +838,21 @@ private:
 			f.primary_lists = (uint64_t)(uintptr_t)_dev.lists;
 			return PT_OK;
 		};
+		// ... and the camera-ray culling masks of a scene of a few triangles in its loop form, fused engine: one small launch per
+		// (camera, scene, pixel range) instead of a part of every render (a fifth of a one-sample call of the reference's scene)
+		const bool masks_now = !walk && engine == PT_ENGINE_FUSED && _nTris <= 64u && !_masksValid && !std::getenv("PT_NEED_MASKS_INLINE");
+		auto build_masks = [&]() -> int {
+			if (!_dev.masks) PT_TRY(pt_hip_malloc(&_dev.masks, pt_hip_need_masks_bytes(_pixelCount)));
+			PT_TRY(pt_hip_build_need_masks(&f, scene, _nTris, _nMats, _dev.masks, _stream));
+			_masksValid = true;
+			return PT_OK;
+		};
 		if (lists_now && Probing()) { if (int rc = build_lists()) return rc; }
+		if (masks_now && Probing()) { if (int rc = build_masks()) return rc; }
 		PT_TRY(pt_hip_event_record(_evStart, _stream));
 		if (lists_now && !_listsValid) { if (int rc = build_lists()) return rc; }
+		if (masks_now && !_masksValid) { if (int rc = build_masks()) return rc; }
+		f.need_masks = !walk && engine == PT_ENGINE_FUSED && _masksValid ? (uint64_t)(uintptr_t)_dev.masks : 0ull;
 		// Several local shards through the fused engine (strided streams: the stream words are only READ, and each shard
 		// writes a mean of its own).  Brute-force scenes in step: all of them in ONE launch (pt_hip_render_fused_shards) --
 		// a launch per shard costs 0.06 ms of a 1.0 ms step (tools/split_cost.py, 1080p, 8 shards x 8 samples).

@@ -257,7 +257,7 @@ __device__ __forceinline__ void bounces_block(const ShadeCtx& c, const float4* _
 				uint32_t traced_acc = 0;                            // wave-uniform: rays this wave traced for bounce 1 in this chunk
 				// which triangles this wave's 64 pixels can see: one word per 64 pixels, worked out before the call's first pass
 				// (need_masks_block) -- it depends on the pixels and the camera only
-				const unsigned long long need = need_masks[li0 / 64u + (threadIdx.x >> 6)];
+				const unsigned long long need = wave_uniform(need_masks[li0 / 64u + (threadIdx.x >> 6)]);
 				if (SEQ) {
 					// SEQUENTIAL streams: sample s+1 of a pixel starts where sample s stopped, so a lane makes its pixel's samples
 					// one after the other for as long as each ends right here (its frame goes into the mean from registers, its

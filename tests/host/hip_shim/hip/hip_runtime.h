@@ -81,6 +81,7 @@ static inline uint32_t shim_wave_lane() { return t_wave ? (threadIdx.x & 63u) : 
 static inline void __syncthreads() { if (t_block) t_block->barrier(); else if (t_wave) t_wave->barrier(); }
 static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 static inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) { return v; }      // (used on values every lane holds alike)
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }

@@ -44,7 +44,7 @@ def test_reference_struct_layouts(pt):
     assert C.sizeof(pt.CameraData) == 36
     cam = pt.CameraData()
     assert list(cam.position) == [0, 0, 0, 1] and list(cam.rotation) == [0, 0, 0, 1] and cam.fieldOfView == 90.0
-    assert C.sizeof(pt.Frame) == 48 + 64
+    assert C.sizeof(pt.Frame) == 56 + 64
 
 
 def test_scene_pack_matches_reference_arithmetic(pt):

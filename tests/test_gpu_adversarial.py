@@ -98,3 +98,60 @@ def test_small_trees_walked_from_lds(pt, oracle, scene_name, depth, strided):
             assert got.rays == st.rays and (strided or np.array_equal(rng, ref_rng))
     finally:
         lib.pt_hip_set_bvh_threshold(pt.PT_BVH_DEFAULT_MIN_TRIANGLES)
+
+
+@pytest.mark.parametrize("strided,out_of_step", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("w,h,first,count", [(200, 33, 0, None), (96, 54, 1000, 96 * 54 - 1777), (64, 40, 0, None), (30, 70, 7, 30 * 70 - 7)])
+def test_need_masks_built_ahead_equal_masks_worked_out_in_the_launch(pt, oracle, w, h, first, count, strided, out_of_step):
+    """pt_hip_build_need_masks + pt_frame.need_masks (the plugin's form: one small launch per camera, a lane per 64 pixels) against the
+    fused kernel working the masks out itself, a triangle per lane: same image, same streams, same ray count -- on the scene whose edges
+    run along pixel boundaries, images whose rows are not multiples of 64 pixels (a wave's pixels span rows) and pixel ranges that
+    start and stop inside a row.  The words are not ~0 (something is culled) and every word past the range is 0."""
+    import ctypes as C
+    from gpu_util import DeviceBuffer, make_frame, sync, upload_scene
+    lib = pt.load_library()
+    V, T, M = pixel_corner_scene(oracle, w, h, 31, 3)
+    scene_dev = upload_scene(pt, lib, pt.make_scene(V, T, M))
+    assert not scene_dev.frame_flags & pt.PT_FRAME_SCENE_BVH
+    n_pix = w * h - first if count is None else count
+    depth, spp = 6, 5
+    flags = scene_dev.frame_flags | (pt.PT_FRAME_OUT_OF_STEP if out_of_step else 0)
+    fr = make_frame(pt, oracle, w, h, pixel_first=first, pixel_count=n_pix, depth=depth, rng_mode=1 if strided else 0, stride=2 + 33 * depth, flags=flags)
+    n_bytes = lib.pt_hip_need_masks_bytes(n_pix)
+    assert n_bytes == ((n_pix + 255) // 256) * 4 * 8
+    masks = DeviceBuffer(lib, n_bytes).upload(np.full(n_bytes // 8, 0xCDCDCDCDCDCDCDCD, dtype=np.uint64))
+    assert lib.pt_hip_build_need_masks(C.byref(fr), scene_dev.ptr, len(T), len(M), masks.ptr, None) == 0, lib.pt_hip_last_error()
+    out = []
+    for ahead in (False, True):
+        fr.need_masks = masks.ptr if ahead else 0
+        rng = DeviceBuffer(lib, n_pix * 4)
+        assert lib.pt_hip_rng_seed(C.byref(fr), rng.ptr, None) == 0
+        mean = DeviceBuffer(lib, n_pix * 16).upload(np.ones(n_pix * 4, dtype=np.float32))
+        stats = DeviceBuffer(lib, pt.PT_STATS_WORDS * 8).upload(np.zeros(pt.PT_STATS_WORDS, dtype=np.uint64))
+        assert lib.pt_hip_render_fused(C.byref(fr), scene_dev.ptr, len(T), len(M), 0, 0, spp, rng.ptr, mean.ptr, stats.ptr, None) == 0, lib.pt_hip_last_error()
+        sync(lib)
+        out.append((mean.download(np.uint32).reshape(n_pix, 4), rng.download(np.uint32), int(stats.download(np.uint64)[0])))
+    diff = (out[0][0] != out[1][0]).any(axis=1)
+    assert not diff.any(), f"{int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2] and out[0][2] > n_pix * spp
+    ref, _, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=spp, **(dict(rng_mode=oracle.RNG_STRIDED, stride=2 + 33 * depth) if strided else {})),
+                                  scene=oracle.make_scene(V, T, M), pixel_first=first, n=n_pix)
+    assert np.array_equal(out[1][0], ref.view(np.uint32).reshape(-1, 4)) and out[1][2] == st.rays
+    words = masks.download(np.uint64)
+    used = (n_pix + 63) // 64
+    full = np.uint64((1 << len(T)) - 1)
+    assert (words[:used] & ~full == 0).all() and (words[:used] != full).any() and (words[:used] != 0).any()
+    assert (words[used:] == 0).all()
+
+
+def test_need_masks_are_for_scenes_without_a_bvh(pt, oracle):
+    import ctypes as C
+    import scenes
+    from gpu_util import DeviceBuffer, make_frame, upload_scene
+    lib = pt.load_library()
+    V, T, M = scenes.synthetic_scene(300)
+    scene_dev = upload_scene(pt, lib, pt.make_scene(V, T, M))
+    fr = make_frame(pt, oracle, 32, 16, flags=scene_dev.frame_flags)
+    masks = DeviceBuffer(lib, lib.pt_hip_need_masks_bytes(32 * 16))
+    assert lib.pt_hip_build_need_masks(C.byref(fr), scene_dev.ptr, len(T), len(M), masks.ptr, None) == -1
+    assert b"BVH" in lib.pt_hip_last_error()
