@@ -93,8 +93,9 @@ typedef struct {
  * triangles are packed TWICE by pt_set_scene -- for the loop over all triangles from LDS and with a BVH -- and the BVH forms of
  * the engines join the candidates the plugin measures on the first renders (pt_options.engine): which is faster depends on how
  * the host renders.  Measured at 48 triangles, depth 16, 1080p (profiles/r03_bvh_crossover.txt): one sample per call -- the
- * reference's frame loop -- 7.3 Grays/s looped, 20.2 through the BVH; 16 samples per call under the reference's streams 24.6 / 28.2;
- * 64 strided samples per call 33.3 / 28.4.  Same bits either way.  PT_SMALL_SCENE_BVH=0 in the environment: the loop only. */
+ * reference's frame loop -- 7.3 Grays/s looped, 20.2 through the BVH (12.9 / 24.7 since the culling masks are built ahead of the
+ * renders, profiles/r03_auto_table.txt); 16 samples per call under the reference's streams 24.6 / 28.2; 64 strided samples per
+ * call 33.3 / 28.4.  Same bits either way.  PT_SMALL_SCENE_BVH=0 in the environment: the loop only. */
 #define PT_BVH_DUAL_MIN_TRIANGLES 16u
 
 const char* pt_last_error(void);
