@@ -144,7 +144,8 @@ class PathTracer final : public IPathTracer {
 	static bool _IsWavefront(uint32_t c) { return c == CandWavefront || c == CandWavefrontWalk; }
 	static bool _IsWalk(uint32_t c) { return c == CandWavefrontWalk || c == CandFusedWalk; }
 	uint32_t _nCands = 1, _probeIdx = 0;        // probing while _probeIdx < _nCands (and _nCands > 1)
-	static constexpr uint32_t kProbeRenders = 2;
+	static constexpr uint32_t kProbeRenders = 2, kProbeRendersShort = 6;     // measured renders per candidate; short renders (below kShortRenderMs) get more
+	static constexpr float kShortRenderMs = 0.25f;
 	uint32_t _probeRep = 0;                     // renders the candidate under measurement has had
 	bool _probeWarm = false;                    // the first render after a (re)start has run: it is not measured (cold caches, first touch of fresh buffers)
 	uint32_t _choice = CandFused, _candInFlight = CandFused;
@@ -758,7 +759,13 @@ private:
 		// render of a tenth of a millisecond measured once made the choice a matter of luck at one sample per call
 		const double rate = ms > 0.0f ? (double)(rays - _raysBefore) / ms : 0.0;
 		if (rate > _candRate[_candInFlight]) _candRate[_candInFlight] = rate;
-		if (++_probeRep < kProbeRenders) return PT_OK;
+		// ... and a render of some tens of microseconds -- one sample per call, the reference's frame loop -- six times: candidates 10 %
+		// apart (the fused engine in and out of step on the reference's scene: 43 against 47 us) were told apart wrongly in one run of
+		// several on two measurements each, and the host then keeps the slower one for good; four more renders cost 0.2 ms once
+		// (PT_PROBE_RENDERS in the environment: that many, whatever the renders take)
+		uint32_t want = ms < kShortRenderMs ? kProbeRendersShort : kProbeRenders;
+		if (const char* e = std::getenv("PT_PROBE_RENDERS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 64) want = (uint32_t)v; }
+		if (++_probeRep < want) return PT_OK;
 		_probeRep = 0;
 		if (++_probeIdx < _nCands) return PT_OK;
 		_choice = _cands[0];

@@ -166,16 +166,20 @@ def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
     has_bvh = len(T) > pt.PT_BVH_DEFAULT_MIN_TRIANGLES
     dual = not has_bvh and len(T) > pt.PT_BVH_DUAL_MIN_TRIANGLES
     # one unmeasured render (a cold device would count against whoever goes first), then two renders per candidate (the better one
-    # counts): BVH scenes have 2 candidates, small scenes held in both forms 5, the rest 3
-    n_probe = 1 + 2 * (2 if has_bvh else 5 if dual else 3)
-    ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=n_probe + 1), scene=oracle.make_scene(V, T, M))
+    # counts) -- six where a render takes less than a quarter of a millisecond, as these do: BVH scenes have 2 candidates, small
+    # scenes held in both forms 5, the rest 3
+    n_cands = 2 if has_bvh else 5 if dual else 3
     with pt.PathTracer(w, h) as tr:
         assert tr.get_options().engine == pt.PT_ENGINE_AUTO
         tr.set_scene(*pt.make_scene(V, T, M))
         assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO and tr.stats().small_scene_dual == (1 if dual else 0)
-        for _ in range(n_probe):
-            assert tr.stats().engine_in_use == pt.PT_ENGINE_AUTO          # still measuring
+        n_probe = 0
+        while tr.stats().engine_in_use == pt.PT_ENGINE_AUTO:                # still measuring
+            assert n_probe < 1 + 6 * n_cands
             tr.render(1)
+            n_probe += 1
+        assert n_probe >= 1 + 2 * n_cands
+        ref, ref_rng, st_ref, _ = oracle.render(oracle.params(w, h, spp=n_probe + 1), scene=oracle.make_scene(V, T, M))
         st = tr.stats()
         assert st.engine_in_use in (pt.PT_ENGINE_FUSED, pt.PT_ENGINE_WAVEFRONT)
         rates = {"wavefront": st.auto_rays_per_ms[0], "fused": st.auto_rays_per_ms[1]}
@@ -205,9 +209,11 @@ def test_engine_auto_probes_then_keeps_one_engine(pt, oracle, scene_name):
     assert_bit_equal(img2, ref2, f"auto on {scene_name} after a camera restart")
 
 
-def test_candidates_are_measured_again_when_the_samples_per_call_change(pt, oracle):
+def test_candidates_are_measured_again_when_the_samples_per_call_change(pt, oracle, monkeypatch):
     """the fastest kernels at one sample per call need not be the fastest at 64: a fourfold change of the samples per render
-    starts the measurement over (the image stays the oracle's throughout)"""
+    starts the measurement over (the image stays the oracle's throughout).  PT_PROBE_RENDERS pins the renders per candidate: renders as
+    short as this test's would get six each (test_engine_auto_probes_then_keeps_one_engine runs that way)."""
+    monkeypatch.setenv("PT_PROBE_RENDERS", "2")
     V, T, M = scenes.all_materials_scene()
     w, h = 160, 90
     with pt.PathTracer(w, h) as tr:

@@ -12,7 +12,7 @@ def rate(sc, depth, shading, kw, engine, spp, force_oos=None):
         with pt.PathTracer(1920, 1080) as tr:
             if sc is not None: tr.set_scene(*sc)
             tr.set_options(engine=engine, depth=depth, shading=shading, **kw)
-            for _ in range(12): tr.render(spp)
+            for _ in range(12 if spp > 4 else 40): tr.render(spp)        # (short renders are measured six times per candidate)
             s0 = tr.stats()
             for _ in range(3): tr.render(spp)
             s1 = tr.stats()

@@ -22,7 +22,7 @@ for n in (48, 108, 192, 300, 432, 588, 972):
                 tr.set_scene(*pt.make_scene(*sc))
                 kw = dict(rng_mode=pt.PT_RNG_STRIDED, stride=2 + 33 * depth, samples_per_pass=16) if strided else {}
                 tr.set_options(engine=pt.PT_ENGINE_AUTO, depth=depth, **kw)
-                for _ in range(12):        # the plugin's own measurement: one unmeasured render, then two per candidate (at most five)
+                for _ in range(12 if spp > 4 else 40):        # the plugin's own measurement: one unmeasured render, then two per candidate (at most five; six each of short renders)
                     tr.render(spp)
                 s0 = tr.stats()
                 for _ in range(2):

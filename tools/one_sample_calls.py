@@ -18,7 +18,7 @@ with pt.PathTracer(1920, 1080) as tr:
     if n_tris:
         tr.set_scene(*pt.make_scene(*scenes.synthetic_scene(n_tris)))
     tr.set_options(engine=engine)
-    for _ in range(20):
+    for _ in range(40):              # the plugin's measurement of its candidates: up to 31 renders of this length
         tr.render(1)
     s0 = tr.stats()
     t0 = time.perf_counter()
