@@ -1602,6 +1602,19 @@ int pt_hip_debug_bvh_counts(unsigned long long* out, int reset) {
 }
 #endif
 
+// Blocks of a k_fused launch: one per 256-pixel tile (above) -- except for a launch of ONE OR TWO samples per pixel, the reference's
+// frame loop, where a block's set-up (its tables go to LDS: a round trip to memory and a barrier before the first pixel is asked
+// for) is a fifth of its life: there the grid is what the machine holds at once and the blocks walk the tiles (same box, 1080p,
+// one sample per call of the reference's scene, uncapped / 6144 / 4096 / 3072 / 2048 / 1536 blocks: 42.7 / 39.6 / 37.6 / 35.4 /
+// 35.1 / 35.7 us; two samples 66.7 -> 64.6; four and more lose: 104.3 -> 107.6, 64: 5 %).  PT_FUSED_GRID_CAP=<blocks> in the
+// environment caps every launch (tests: pixel loops of several trips on small images).
+static unsigned fused_grid_blocks(uint32_t pixel_count, uint64_t samples_per_pixel, int mode) {
+	size_t blocks = ((size_t)pixel_count + kBlock - 1) / kBlock;
+	if (const char* e = std::getenv("PT_FUSED_GRID_CAP")) blocks = std::min<size_t>(blocks, (size_t)std::max(1, std::atoi(e)));
+	else if (mode != 2 && samples_per_pixel <= 2u) blocks = std::min<size_t>(blocks, (size_t)grid_for((size_t)1 << 40));
+	return (unsigned)blocks;
+}
+
 int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t n_triangles, uint32_t n_materials,
                         uint32_t frame_first, uint32_t mean_first, uint32_t n_samples,
                         uint32_t* rng, void* mean, uint64_t* stats, void* stream) {
@@ -1628,7 +1641,7 @@ int pt_hip_render_fused(const pt_frame* frame, const void* scene_blob, uint32_t 
 	// hardware scheduler back-filling 8100 short-lived blocks beats any persistent grid-stride
 	// grid (145 vs 131 Grays/s at 8 blocks/CU) because the kernel holds 77 VGPRs = 6 waves/SIMD and a
 	// persistent grid sized for 8 leaves a one-third-full tail round.
-	dim3 grid((unsigned)(((size_t)frame->pixel_count + kBlock - 1) / kBlock)), block(kBlock);
+	dim3 grid(fused_grid_blocks(frame->pixel_count, n_samples, mode)), block(kBlock);
 #define PT_FUSED(STR, MODE) hipLaunchKernelGGL((k_fused<STR, MODE, false>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, 1u, 0u, rng, (float4*)mean, (unsigned long long*)stats)
 	if (mode == 2 && !fused_bvh_plain()) {
@@ -1691,7 +1704,7 @@ int pt_hip_render_fused_shards(const pt_frame* frame, const void* scene_blob, ui
 	for (uint32_t k = 0; k < n_shards; k++) host_jump_matrix((uint64_t)frame_first[k] * frame->stride, first.cols + 32u * k);
 	host_jump_matrix(frame->stride, per.cols);
 	size_t lds_bytes = (mode == 1 ? shade_lds_bytes(si) : 0) + (si.n_tris <= kPrimMaxTris ? (size_t)si.n_tris * sizeof(PrimRec) : 0);
-	dim3 grid((unsigned)(((size_t)frame->pixel_count + kBlock - 1) / kBlock)), block(kBlock);
+	dim3 grid(fused_grid_blocks(frame->pixel_count, (uint64_t)n_samples * n_shards, mode)), block(kBlock);
 #define PT_FUSED_SHARDS(MODE) hipLaunchKernelGGL((k_fused<true, MODE, false, PT_FUSED_MAX_SHARDS>), grid, block, lds_bytes, s, f, (const unsigned char*)scene_blob, si.n_tris, si.n_mats, first, per, \
 	mean_first, n_samples, n_shards, (uint32_t)mean_pitch_pixels, rng, (float4*)mean, (unsigned long long*)stats)
 	if (mode == 1) PT_FUSED_SHARDS(1); else PT_FUSED_SHARDS(0);

@@ -155,3 +155,43 @@ def test_need_masks_are_for_scenes_without_a_bvh(pt, oracle):
     masks = DeviceBuffer(lib, lib.pt_hip_need_masks_bytes(32 * 16))
     assert lib.pt_hip_build_need_masks(C.byref(fr), scene_dev.ptr, len(T), len(M), masks.ptr, None) == -1
     assert b"BVH" in lib.pt_hip_last_error()
+
+
+@pytest.mark.parametrize("cap", ["1", "3", "7"])
+@pytest.mark.parametrize("strided,out_of_step", [(False, False), (True, False), (False, True)])
+def test_fused_pixel_loop_of_several_trips(pt, oracle, monkeypatch, cap, strided, out_of_step):
+    """A launch of one or two samples per pixel runs on as many blocks as the machine holds at once and its blocks walk the 256-pixel
+    tiles (fused_grid_blocks) -- 1080p on a whole MI355X: four trips.  PT_FUSED_GRID_CAP forces that loop on a small image: blocks
+    that take several tiles, the last of them partial, some none at all; with the culling masks built ahead, against the oracle."""
+    monkeypatch.setenv("PT_FUSED_GRID_CAP", cap)
+    if out_of_step:
+        monkeypatch.setenv("PT_FUSED_OUT_OF_STEP", "1")
+    w, h, depth = 100, 37, 6                                   # 3700 pixels: 14.45 tiles
+    V, T, M = pixel_corner_scene(oracle, w, h, 20, 11)
+    mode = dict(rng_mode=oracle.RNG_STRIDED, stride=2 + 33 * depth) if strided else {}
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, depth=depth, spp=4, **mode), scene=oracle.make_scene(V, T, M))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_scene(*pt.make_scene(V, T, M))
+        kw = dict(rng_mode=pt.PT_RNG_STRIDED, stride=2 + 33 * depth) if strided else {}
+        tr.set_options(engine=pt.PT_ENGINE_FUSED, depth=depth, **kw)
+        for n in (1, 2, 1):
+            tr.render(n)
+        img, rng, got = tr.readback(), tr.readback_rng(), tr.stats()
+    diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+    assert not diff.any(), f"{int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+    assert got.rays == st.rays and (strided or np.array_equal(rng, ref_rng))
+
+
+def test_one_sample_calls_at_1080p(pt, oracle):
+    """the reference's frame loop at its size: three calls of one sample on the capped grid (four tiles per block on a whole MI355X),
+    every pixel against the oracle"""
+    w, h = 1920, 1080
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, spp=3))
+    with pt.PathTracer(w, h) as tr:
+        tr.set_options(engine=pt.PT_ENGINE_FUSED)
+        for _ in range(3):
+            tr.render(1)
+        img, rng, got = tr.readback(), tr.readback_rng(), tr.stats()
+    diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+    assert not diff.any(), f"{int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
+    assert np.array_equal(rng, ref_rng) and got.rays == st.rays
