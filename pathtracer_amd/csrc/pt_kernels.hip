@@ -1443,7 +1443,11 @@ static int render_wavefront_impl(const pt_frame* frame, const void* scene_blob, 
 	// whose blocks own pixel chunks -- the queue geometry of the whole pass follows it
 	const bool camera_fused = !fuse && scene_has_bvh(si) && f.primary_lists != nullptr && !std::getenv("PT_CAMERA_STAGED");
 	// queue blocks: fixed for every stage of every pass
-	const uint32_t G = (uint32_t)(fuse ? grid_for_pass(frame->pixel_count) : camera_fused ? grid_for_chunks(frame->pixel_count) : grid_for(paths_cap));
+	// (the one-launch pass of a call of one or two samples: the blocks the machine holds at once, each taking several chunks -- a block's
+	// set-up is a fifth of so short a life, as in the fused engine (fused_grid_blocks); the queues' capacity covers that grid too)
+	const bool short_call = fuse && n_samples <= 2u && !std::getenv("PT_PASS_GRID_FULL");
+	const uint32_t G = (uint32_t)(short_call ? grid_for_chunks(frame->pixel_count) : fuse ? grid_for_pass(frame->pixel_count)
+	                              : camera_fused ? grid_for_chunks(frame->pixel_count) : grid_for(paths_cap));
 	const uint32_t slots = (uint32_t)queue_capacity(frame->pixel_count, samples_per_pass);
 	// what the stages take as the queues' capacity: the identity queue's path count, or every slot a chunk-owning block can reach
 	const uint32_t stage_cap = camera_fused ? (uint32_t)owned_slots_tiles(frame->pixel_count, samples_per_pass, G) : (uint32_t)paths_cap;

@@ -182,15 +182,16 @@ def test_fused_pixel_loop_of_several_trips(pt, oracle, monkeypatch, cap, strided
     assert got.rays == st.rays and (strided or np.array_equal(rng, ref_rng))
 
 
-def test_one_sample_calls_at_1080p(pt, oracle):
-    """the reference's frame loop at its size: three calls of one sample on the capped grid (four tiles per block on a whole MI355X),
-    every pixel against the oracle"""
+@pytest.mark.parametrize("name,engine", [("fused", 1), ("wavefront", 0)])
+def test_one_sample_calls_at_1080p(pt, oracle, name, engine):
+    """the reference's frame loop at its size: calls of one and two samples on the capped grids (four tiles or chunks per block on a
+    whole MI355X: fused_grid_blocks, and the one-launch pass's grid in pt_hip_render_wavefront), every pixel against the oracle"""
     w, h = 1920, 1080
-    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, spp=3))
+    ref, ref_rng, st, _ = oracle.render(oracle.params(w, h, spp=4))
     with pt.PathTracer(w, h) as tr:
-        tr.set_options(engine=pt.PT_ENGINE_FUSED)
-        for _ in range(3):
-            tr.render(1)
+        tr.set_options(engine=engine)
+        for n in (1, 2, 1):
+            tr.render(n)
         img, rng, got = tr.readback(), tr.readback_rng(), tr.stats()
     diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
     assert not diff.any(), f"{int(diff.sum())} pixels differ, first {int(np.argmax(diff))}"
