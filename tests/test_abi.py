@@ -101,6 +101,11 @@ def test_argument_checks_precede_device_work(pt):
     fr = pt.Frame(width=8, height=8, pixel_first=0, pixel_count=64, depth=10, rng_mode=1, stride=0)
     assert lib.pt_hip_rng_seed(C.byref(fr), None, None) == -1 and b"stride" in lib.pt_hip_last_error()
     assert lib.pt_hip_combine_shards(None, 4, 16, None, None) == -1
+    fr = pt.Frame(width=8, height=8, pixel_first=0, pixel_count=64, depth=10)
+    assert lib.pt_hip_build_need_masks(C.byref(fr), None, 4, 2, None, None) == -1 and b"null pointer" in lib.pt_hip_last_error()
+    assert lib.pt_hip_build_need_masks(None, None, 4, 2, None, None) == -1
+    # one 64-bit word per 64 pixels, in whole blocks of 256 pixels
+    assert [lib.pt_hip_need_masks_bytes(n) for n in (1, 256, 257, 1920 * 1080)] == [32, 32, 64, 8100 * 32]
     assert lib.pt_update(None, None) == -1 and b"null handle" in lib.pt_last_error()
     assert lib.pt_render(None, 1) == -1
     assert lib.pt_readback(None, None, 0) == -1
